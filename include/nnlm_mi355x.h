@@ -1,0 +1,160 @@
+/*
+ * nnlm_mi355x.h -- C ABI of libnnlm_mi355x.so: the MI355X (gfx950) implementation of the hot
+ * path of the R package linxihui/NNLM (alternating nnmf() loop + single-solve nnlm()).
+ *
+ * This header is the drop-in boundary.  The reference's FFI for this path is the pair of
+ * registered .Call routines `_NNLM_c_nnmf` (17 SEXP args) and `_NNLM_c_nnlm` (9 SEXP args)
+ * (reference src/RcppExports.cpp:10-27, :29-54, :56-65; called from R/RcppExports.R:4-10).
+ * `nnlm_c_nnmf()` / `nnlm_c_nnlm()` below take exactly those arguments as plain pointers and
+ * sizes and return exactly the members of the reference's named result lists
+ * (src/nnmf.cpp:211-219, src/nnlm.cpp:49-52).  nnlm_amd/csrc/r_glue.c shows the Rinternals-only
+ * .Call stub a maintainer adds on the R side; nnlm_amd/_lib.py is the ctypes binding used here.
+ *
+ * Conventions (all taken from the reference):
+ *   - every matrix is column-major (R / Armadillo), fp64 at the boundary;
+ *   - logical masks are `int` arrays (R LGLSXP), non-zero = masked (entry is never updated);
+ *   - missing entries of A / y are any non-finite value (NA, NaN, +-Inf), src/nnmf.cpp:65-68;
+ *   - method: 1 scd+mse, 2 lee+mse, 3 scd+mkl, 4 lee+mkl (R/misc.R:28-35);
+ *   - alpha/beta: [L2, angle, L1] (src/nnmf.cpp:19-20).
+ * Inputs are never written.  No exceptions cross this ABI: every function returns NNLM_OK or an
+ * error code and leaves a message retrievable with nnlm_last_error().
+ */
+#ifndef NNLM_MI355X_H
+#define NNLM_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNLM_ABI_VERSION 1
+
+/* return codes */
+#define NNLM_OK 0
+#define NNLM_ERR_ARG 1       /* invalid argument (the reference would throw from Armadillo / R stop()) */
+#define NNLM_ERR_HIP 2       /* HIP runtime failure (no device, out of memory, launch failure) */
+#define NNLM_ERR_INTERRUPT 3 /* the check_interrupt callback asked to stop (Rcpp::checkUserInterrupt) */
+#define NNLM_ERR_COMM 4      /* RCCL failure */
+#define NNLM_ERR_UNSUPPORTED 5
+
+/* arithmetic modes: what A is stored as in HBM and which MFMA the cross-products run on.
+ * Gram matrices, mu = G*x - c, the coordinate sweeps and all reductions are fp64 in both modes. */
+#define NNLM_PREC_F32 0 /* A and GEMM operands fp32, v_mfma_f32_16x16x4_f32, fp32 partial sums flushed into fp64 */
+#define NNLM_PREC_F64 1 /* A and GEMM operands fp64, v_mfma_f64_16x16x4_f64 (strict-parity mode) */
+
+/*
+ * Host callbacks = the R API points the reference touches from its main thread.
+ * Any member (or the whole struct pointer) may be NULL.
+ */
+typedef struct nnlm_callbacks {
+    void *ctx;
+    int (*check_interrupt)(void *ctx);                        /* src/nnmf.cpp:111; non-zero aborts the run */
+    void (*progress)(void *ctx, unsigned done, unsigned total); /* RcppProgress increment, src/nnmf.cpp:60,112 (verbose==1) */
+    void (*print)(void *ctx, const char *text);               /* Rprintf, src/nnmf.cpp:100-104,155-156,188-189,194-198 (verbose==2) */
+    void (*warning)(void *ctx, const char *text);             /* Rcpp::warning, src/nnmf.cpp:208-209 */
+    double (*unif_rand)(void *ctx);                           /* R's RNG behind arma::randu, src/nnmf.cpp:84,94; src/nnlm.cpp:39 */
+} nnlm_callbacks;
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot entries (what `.Call("_NNLM_c_nnmf", ...)` / `.Call("_NNLM_c_nnlm", ...)` bind to)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Length the four trace vectors must have: ceil(max_iter/trace)+1 (src/nnmf.cpp:53-54). */
+unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace);
+
+/*
+ * Replaces c_nnmf (reference src/nnmf.cpp:4-220; signature src/RcppExports.cpp:29-51).
+ *   A        n x m, const, may contain non-finite = missing
+ *   k        rank K (already includes known-profile columns, R/misc.R:84)
+ *   W_init   n x k initial W, or NULL for the default 0.01*U(0,1) init (src/nnmf.cpp:82-88)
+ *   H_init   k x m initial H, or NULL (src/nnmf.cpp:92-98)
+ *   Wm, Hm   n x k / k x m logical masks, or NULL when empty (src/nnmf.cpp:75-80)
+ *   n_threads accepted for signature compatibility; the GPU path ignores it
+ * Outputs (caller-allocated): W_out n x k, H_out k x m, four traces of nnlm_trace_capacity()
+ * doubles each with *n_trace entries used (src/nnmf.cpp:200-206), *n_iteration (src/nnmf.cpp:218),
+ * *warned = 1 iff the reference would have raised "Target tolerance not reached. Try a larger
+ * max.iter." (src/nnmf.cpp:208-209; the text is also passed to cb->warning).
+ */
+int nnlm_c_nnmf(const double *A, int n, int m, unsigned k,
+                const double *W_init, const double *H_init, const int *Wm, const int *Hm,
+                const double alpha[3], const double beta[3],
+                unsigned max_iter, double rel_tol, int n_threads, int verbose, int show_warning,
+                unsigned inner_max_iter, double inner_rel_tol, int method, unsigned trace,
+                double *W_out, double *H_out,
+                double *mse_error, double *mkl_error, double *target_error, double *average_epoch,
+                int *n_trace, unsigned *n_iteration, int *warned,
+                const nnlm_callbacks *cb);
+
+/*
+ * Replaces c_nnlm (reference src/nnlm.cpp:4-53; signature src/RcppExports.cpp:10-27).
+ *   x n x p, y n x q (may contain missing), mask p x q or NULL, beta0 p x q or NULL (-> U(0,1) init).
+ * Outputs: coefficient p x q, *n_iteration = summed per-column sweeps (src/nnlm.cpp:44-51).
+ */
+int nnlm_c_nnlm(const double *x, const double *y, int n, int p, int q,
+                const double alpha[3], const int *mask, const double *beta0,
+                unsigned max_iter, double rel_tol, int n_threads, int method,
+                double *coefficient, int *n_iteration, const nnlm_callbacks *cb);
+
+/* ------------------------------------------------------------------------------------------
+ * Resident API: the same path with A kept in HBM across calls.  The one-shot entries are thin
+ * wrappers over it; bench.py and the parity tests of single half-steps use it directly.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct nnlm_handle nnlm_handle;
+
+/* device = HIP device ordinal; precision = NNLM_PREC_*.  Fails loudly when no gfx950 device exists. */
+int nnlm_create(nnlm_handle **out, int device, int precision);
+void nnlm_destroy(nnlm_handle *h);
+const char *nnlm_last_error(const nnlm_handle *h); /* h may be NULL: error of the last failed nnlm_create / one-shot call */
+int nnlm_abi_version(void);
+
+/* Upload A (n x m, fp64, column-major).  One pass on the device converts to the resident layout,
+ * finds the non-finite entries (src/nnmf.cpp:65-69) and sums the constant KL part (src/nnmf.cpp:70,73). */
+int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m);
+/* Number of finite entries of A (N_non_missing, src/nnmf.cpp:51,69) and the any_missing flag. */
+int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_missing, double *kl_const);
+
+/* Set rank, factors (W n x k, H k x m; NULL = zeros) and masks (NULL = none). */
+int nnlm_set_factors(nnlm_handle *h, unsigned k, const double *W, const double *H, const int *Wm, const int *Hm);
+int nnlm_get_factors(nnlm_handle *h, double *W, double *H);
+
+/*
+ * One half-step = update()/update_with_missing() (reference src/update_with_missing.cpp:3-55, :58-139).
+ * which = 0 updates W (solves A^T ~ H^T W^T with `reg` = alpha), 1 updates H (`reg` = beta).
+ * Asynchronous on the handle's stream; the integer sweep count is accumulated on the device.
+ */
+int nnlm_half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter,
+                   double inner_rel_tol, int method);
+/* n_iter outer iterations (W half-step then H half-step, src/nnmf.cpp:114-133), asynchronous. */
+int nnlm_iterate(nnlm_handle *h, unsigned n_iter, const double alpha[3], const double beta[3],
+                 unsigned inner_max_iter, double inner_rel_tol, int method);
+/* Summed per-column sweeps since the last reset (total_raw_iter, src/nnmf.cpp:106,158); synchronises. */
+int nnlm_take_sweeps(nnlm_handle *h, long long *sweeps, int reset);
+/* Error block (src/nnmf.cpp:121-126,135-140): mse = mean((A-WH)^2), mkl_var = mean(-(A+eps)log(WH+eps)+WH)
+ * over finite entries, plus the penalty sums add_penalty() needs (src/nnmf.cpp:224-240):
+ * pen[0..2] = sum(W^2), sum over i of (sum_q W[i,q])^2, sum(W); pen[3..5] the same for H.  Synchronises. */
+int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double pen[6]);
+int nnlm_sync(nnlm_handle *h);
+
+/* Per-kernel device timing (HIP events on the handle's stream) for bench.py's roofline block.
+ * names: "xprod_h" (A-streaming W^T A), "xprod_w" (A H^T), "gram", "sweep_h", "sweep_w", "errors". */
+int nnlm_profile_enable(nnlm_handle *h, int on);
+int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_ms, long long *launches);
+int nnlm_profile_reset(nnlm_handle *h);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated; each rank contracts its
+ * slab of rows (H half-step) / columns (W half-step) and the partial [Gram | cross-product]
+ * buffer is summed with ONE ncclAllReduce per half-step; the sweep then runs replicated.
+ * ---------------------------------------------------------------------------------------- */
+#define NNLM_COMM_ID_BYTES 128
+int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */
+int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES], int rank, int nranks);
+/* Shard description without a communicator (virtual ranks, single-device tests): the handle
+ * computes only rank `rank`'s slab of an `nranks`-way split and leaves the partial sums in place. */
+int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNLM_MI355X_H */

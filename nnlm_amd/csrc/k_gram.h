@@ -1,0 +1,95 @@
+// k_gram.h -- k x k Gram matrix of the fixed factor of a half-step, in fp64.
+// Reference: `WtW = Wt * Wt.t()` at the top of update(), src/update_with_missing.cpp:19
+// (the regularisation edits of :20-24 are applied where G is consumed, see k_sweep.h).
+//
+//   gram_partial : block b contracts 256 columns of X ([KP][ld], fp64 master copy, zero padded)
+//                  with v_mfma_f64_16x16x4_f64 and writes one KP x KP slab (upper tiles only);
+//   gram_reduce  : sums the slabs in a fixed order and mirrors the lower tiles.
+// Work is O(k^2 n) = 1e8 flops at config 2 -- off the roofline; these kernels only have to be short.
+#pragma once
+#include "common.h"
+
+#define GRAM_COLS_PER_BLOCK 256
+
+template <int NKQ>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restrict__ X, int ld, int c_begin, int c_end,
+                                                           double *__restrict__ slabs)
+{
+    constexpr int KP = 16 * NKQ;
+    __shared__ double red[KP * KP]; // waves 3,2,1 fold their tiles here in turn (fixed order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int c0 = c_begin + blockIdx.x * GRAM_COLS_PER_BLOCK + wave * 64;
+
+    f64x4 acc[NKQ][NKQ];
+#pragma unroll
+    for (int a = 0; a < NKQ; a++)
+#pragma unroll
+        for (int b = 0; b < NKQ; b++) acc[a][b] = f64x4{0, 0, 0, 0};
+
+    // 8 columns per step: lane holds X[16t + l15][c + 2*lg + e], e = 0,1
+    for (int c = c0; c < c0 + 64 && c < c_end; c += 8) {
+        f64x2 x[NKQ];
+#pragma unroll
+        for (int t = 0; t < NKQ; t++) x[t] = *(const f64x2 *)(X + (size_t)(16 * t + l15) * ld + c + 2 * lg);
+        if (c + 8 > c_end) { // ragged end of a slab range (multi-GPU split): drop columns >= c_end
+#pragma unroll
+            for (int t = 0; t < NKQ; t++) {
+                if (c + 2 * lg >= c_end) x[t][0] = 0.0;
+                if (c + 2 * lg + 1 >= c_end) x[t][1] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int a = 0; a < NKQ; a++)
+#pragma unroll
+                for (int b = a; b < NKQ; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[a][e], x[b][e], acc[a][b], 0, 0, 0);
+    }
+    // f64 C/D layout: reg r -> row lg + 4r, col l15
+    for (int w = 3; w >= 1; --w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NKQ; a++)
+#pragma unroll
+                for (int b = a; b < NKQ; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int idx = (16 * a + lg + 4 * r) * KP + 16 * b + l15;
+                        red[idx] = (w == 3) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        double *out = slabs + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+        for (int a = 0; a < NKQ; a++)
+#pragma unroll
+            for (int b = a; b < NKQ; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int idx = (16 * a + lg + 4 * r) * KP + 16 * b + l15;
+                    out[idx] = red[idx] + acc[a][b][r];
+                }
+    }
+}
+
+// G[a][b] = sum over slabs (fixed order); entries of lower tiles are read from the mirrored upper tile.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ slabs, int nslabs, int KP,
+                                                          double *__restrict__ G)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= KP * KP) return;
+    int a = idx / KP, b = idx % KP;
+    if ((a >> 4) > (b >> 4)) {
+        const int t = a;
+        a = b;
+        b = t;
+    }
+    const size_t src = (size_t)a * KP + b;
+    double s = 0.0;
+    for (int i = 0; i < nslabs; i++) s += slabs[(size_t)i * KP * KP + src];
+    G[idx] = s;
+}

@@ -1,0 +1,278 @@
+// k_xprod.h -- the two A-streaming skinny GEMMs of a half-step.
+//
+// Reference: the per-column gemv `Wt * A.col(j)` inside update()'s OpenMP loop
+// (src/update_with_missing.cpp:39,45) and, for the W half-step, the same on the materialised
+// `A.t()` (src/nnmf.cpp:131).  Here both are one pass over the SAME resident column-major A:
+//
+//   xprod_tn : C[kq, j] = sum_i Y[kq, i] * A[i, j]   (H half-step, Y = W^T, contraction contiguous)
+//   xprod_nt : C[kq, i] = sum_j Y[kq, j] * A[i, j]   (W half-step, Y = H,   contraction strided)
+//
+// so A.t() is never formed.  Both are split-K: block (x, s) contracts stage range s of tile x and
+// writes an fp64 slab Cx[s][KP][ldc]; the consumer (sweep kernel, or the slab reduce ahead of the
+// RCCL all-reduce) sums the slabs in a fixed order -> deterministic.
+//
+// MFMA: 16x16x4 (f32 or f64 inputs), one operand element per lane.  Tiles of A and of the factor
+// go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered; operand
+// fragments come out of LDS as 16-byte ds_read_b128.  In f32 mode partial sums are kept in f32
+// for at most XPROD_FLUSH_ELEMS contraction elements and then folded into fp64 accumulators
+// (SURVEY.md section 7 "precision ladder").
+//
+// All operands are zero padded to full tiles, so there are no bounds checks in the hot loop.
+#pragma once
+#include "common.h"
+
+#define XPROD_THREADS 256
+#define XPROD_FLUSH_ELEMS 256
+#define XPROD_ROWB 256            // bytes per LDS row of the TN images (one 16-lane group per row)
+#define XPROD_TN_BJ 128           // columns j per block (TN)
+#define XPROD_NT_ROWS 32          // contraction rows j per stage (NT)
+#define XPROD_A_IMG_BYTES 32768   // A image per stage, both kernels
+
+__host__ __device__ static inline int xprod_tn_lds_bytes(int KP) { return 2 * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB); }
+template <typename T> __host__ __device__ static inline int xprod_nt_lds_bytes(int KP)
+{
+    return 2 * (XPROD_A_IMG_BYTES + XPROD_NT_ROWS * KP * (int)sizeof(T));
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: contraction along i (contiguous in memory).
+//   A      [mpad][lda]  (column j at j*lda), Yop [KP][ldy] (row kq, i fastest)
+//   Cx     [S][KP][ldc] fp64, ldc >= mpad
+//   grid   (mpad/128, S); stage = 256 bytes of contraction per row (64 f32 / 32 f64)
+// LDS image per stage: rows of 256 B; row r holds its sixteen 16-byte slots XOR-swizzled
+// (physical slot = logical slot ^ (r & 15)) so that the fragment reads (16 lanes = 16 different
+// rows, same logical slot) are bank-conflict free.  global_load_lds writes LDS linearly, so the
+// swizzle is applied to the per-lane GLOBAL source address (cdna_hip_programming.md rule 21).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NKQ>
+__global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__restrict__ A, int lda,
+                                                                 const T *__restrict__ Yop, int ldy,
+                                                                 double *__restrict__ Cx, int ldc, size_t slab_stride,
+                                                                 int stage_begin, int stage_end, int stages_per_split)
+{
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    constexpr int EPV = M::EPV;
+    constexpr int KP = 16 * NKQ;
+    constexpr int CE = XPROD_ROWB / (int)sizeof(T); // contraction elements per stage
+    constexpr int BUF = XPROD_A_IMG_BYTES + KP * XPROD_ROWB;
+    constexpr int FL = XPROD_FLUSH_ELEMS / CE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int j0 = blockIdx.x * XPROD_TN_BJ;
+    int st0 = stage_begin + blockIdx.y * stages_per_split;
+    int st1 = st0 + stages_per_split;
+    if (st1 > stage_end) st1 = stage_end;
+
+    acc_t acc[2][NKQ];
+    f64x4 acc64[2][NKQ];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NKQ; b++) {
+            acc[a][b] = acc_t{0, 0, 0, 0};
+            acc64[a][b] = f64x4{0, 0, 0, 0};
+        }
+
+    auto issue = [&](int st, unsigned char *buf) {
+        const size_t i0 = (size_t)st * CE;
+#pragma unroll
+        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += 4) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(A + (size_t)(j0 + row) * lda + i0 + s * EPV, buf + t * 1024);
+        }
+#pragma unroll
+        for (int t = wave; t < KP / 4; t += 4) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(Yop + (size_t)row * ldy + i0 + s * EPV, buf + XPROD_A_IMG_BYTES + t * 1024);
+        }
+    };
+
+    if (st0 < st1) issue(st0, smem);
+    int since_flush = 0;
+    for (int st = st0; st < st1; ++st) {
+        unsigned char *buf = smem + ((st - st0) & 1) * BUF;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * BUF);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int phys = ((lg + 4 * kk) ^ l15) * 16;
+            T a[2][EPV], b[NKQ][EPV];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                const int row = 32 * wave + 16 * mt + l15;
+                const f32x4 raw = *(const f32x4 *)(buf + row * XPROD_ROWB + phys);
+                __builtin_memcpy(a[mt], &raw, 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NKQ; nt++) {
+                const int row = 16 * nt + l15;
+                const f32x4 raw = *(const f32x4 *)(buf + XPROD_A_IMG_BYTES + row * XPROD_ROWB + phys);
+                __builtin_memcpy(b[nt], &raw, 16);
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; e++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NKQ; nt++) acc[mt][nt] = M::mma(a[mt][e], b[nt][e], acc[mt][nt]);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (++since_flush == FL) {
+                since_flush = 0;
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < NKQ; b++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc64[a][b][r] += (double)acc[a][b][r];
+                        acc[a][b] = acc_t{0, 0, 0, 0};
+                    }
+            }
+        }
+    }
+    // epilogue: D[M = j-row, N = kq]
+    double *out = Cx + (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NKQ; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kq = 16 * nt + l15;
+                const int j = j0 + 32 * wave + 16 * mt + M::row_of(lane, r);
+                double v;
+                if constexpr (sizeof(T) == 4) v = acc64[mt][nt][r] + (double)acc[mt][nt][r];
+                else v = acc[mt][nt][r];
+                out[(size_t)kq * ldc + j] = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT: contraction along j (stride lda in memory).
+//   A      [mpad][lda], Yop [mpad][KP] (row j, kq fastest), Cx [S][KP][ldc] fp64, ldc >= npad
+//   grid   (npad/BI, S) with BI = 64*EPV output rows i per block (256 f32 / 128 f64)
+//   stage  = 32 contraction rows j; an image row is 1 KiB of one column of A = one
+//            global_load_lds instruction.  Fragment reads walk 16-byte slots inside a row
+//            (16 lanes) and 4 consecutive rows (lane groups): conflict free without a swizzle.
+// Lane (l&15) of an A fragment holds EPV consecutive i (one per M-tile e); lane (l&15) of a factor
+// fragment holds NKQ consecutive kq (one per N-tile t): the MFMA row/column <-> (i, kq) map is a
+// permutation that is undone in the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NKQ>
+__global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__restrict__ A, int lda,
+                                                                 const T *__restrict__ Yop,
+                                                                 double *__restrict__ Cx, int ldc, size_t slab_stride,
+                                                                 int stage_begin, int stage_end, int stages_per_split)
+{
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    constexpr int EPV = M::EPV;
+    constexpr int KP = 16 * NKQ;
+    constexpr int BI = 64 * EPV;
+    constexpr int YROW = KP * (int)sizeof(T);          // bytes of one factor row
+    constexpr int YIMG = XPROD_NT_ROWS * YROW;         // bytes of the factor image (multiple of 1 KiB)
+    constexpr int BUF = XPROD_A_IMG_BYTES + YIMG;
+    constexpr int FL = XPROD_FLUSH_ELEMS / XPROD_NT_ROWS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int i0 = blockIdx.x * BI;
+    int st0 = stage_begin + blockIdx.y * stages_per_split;
+    int st1 = st0 + stages_per_split;
+    if (st1 > stage_end) st1 = stage_end;
+
+    acc_t acc[EPV][NKQ];
+    f64x4 acc64[EPV][NKQ];
+#pragma unroll
+    for (int a = 0; a < EPV; a++)
+#pragma unroll
+        for (int b = 0; b < NKQ; b++) {
+            acc[a][b] = acc_t{0, 0, 0, 0};
+            acc64[a][b] = f64x4{0, 0, 0, 0};
+        }
+
+    auto issue = [&](int st, unsigned char *buf) {
+        const size_t jb = (size_t)st * XPROD_NT_ROWS;
+#pragma unroll
+        for (int t = wave; t < XPROD_NT_ROWS; t += 4)
+            glds16(A + (jb + t) * lda + i0 + lane * EPV, buf + t * 1024);
+        const unsigned char *ysrc = (const unsigned char *)(Yop + jb * KP);
+#pragma unroll
+        for (int u = wave; u < YIMG / 1024; u += 4)
+            glds16(ysrc + u * 1024 + lane * 16, buf + XPROD_A_IMG_BYTES + u * 1024);
+    };
+
+    if (st0 < st1) issue(st0, smem);
+    int since_flush = 0;
+    for (int st = st0; st < st1; ++st) {
+        unsigned char *buf = smem + ((st - st0) & 1) * BUF;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * BUF);
+#pragma unroll
+        for (int kk = 0; kk < XPROD_NT_ROWS / 4; kk++) {
+            const int row = lg + 4 * kk;
+            T a[EPV], b[NKQ];
+            {
+                const f32x4 raw = *(const f32x4 *)(buf + row * 1024 + wave * 256 + l15 * 16);
+                __builtin_memcpy(a, &raw, 16);
+            }
+            {
+                const unsigned char *p = buf + XPROD_A_IMG_BYTES + row * YROW + l15 * (NKQ * (int)sizeof(T));
+                if constexpr (NKQ * sizeof(T) == 16) {
+                    const f32x4 raw = *(const f32x4 *)p;
+                    __builtin_memcpy(b, &raw, 16);
+                } else if constexpr (NKQ * sizeof(T) == 32) {
+                    const f32x4 r0 = *(const f32x4 *)p, r1 = *(const f32x4 *)(p + 16);
+                    __builtin_memcpy(b, &r0, 16);
+                    __builtin_memcpy((unsigned char *)b + 16, &r1, 16);
+                } else if constexpr (NKQ * sizeof(T) == 8) {
+                    const double raw = *(const double *)p;
+                    __builtin_memcpy(b, &raw, 8);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NKQ; t++) b[t] = ((const T *)p)[t];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; e++)
+#pragma unroll
+                for (int t = 0; t < NKQ; t++) acc[e][t] = M::mma(a[e], b[t], acc[e][t]);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (++since_flush == FL) {
+                since_flush = 0;
+#pragma unroll
+                for (int a = 0; a < EPV; a++)
+#pragma unroll
+                    for (int b = 0; b < NKQ; b++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc64[a][b][r] += (double)acc[a][b][r];
+                        acc[a][b] = acc_t{0, 0, 0, 0};
+                    }
+            }
+        }
+    }
+    // epilogue: tile (e, t): M index -> i = i0 + wave*16*EPV + EPV*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t
+    double *out = Cx + (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int e = 0; e < EPV; e++)
+#pragma unroll
+        for (int t = 0; t < NKQ; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kq = NKQ * l15 + t;
+                const int i = i0 + wave * 16 * EPV + EPV * M::row_of(lane, r) + e;
+                double v;
+                if constexpr (sizeof(T) == 4) v = acc64[e][t][r] + (double)acc[e][t][r];
+                else v = acc[e][t][r];
+                out[(size_t)kq * ldc + i] = v;
+            }
+}

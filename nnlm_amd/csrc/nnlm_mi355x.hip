@@ -1,0 +1,907 @@
+// nnlm_mi355x.hip -- host side of libnnlm_mi355x.so: device-resident state (nnlm_handle), kernel
+// launches for one half-step, the alternating driver restating c_nnmf / c_nnlm, and the C ABI of
+// include/nnlm_mi355x.h.  gfx950 only; no CPU fallback: every entry fails with NNLM_ERR_HIP when no
+// device is present.
+//
+// Reference map (relative to /root/reference):
+//   nnlm_c_nnmf      <- c_nnmf            src/nnmf.cpp:4-220
+//   nnlm_c_nnlm      <- c_nnlm            src/nnlm.cpp:4-53
+//   half_step()      <- update()          src/update_with_missing.cpp:3-55
+//                       update_with_missing()  src/update_with_missing.cpp:58-139
+//   penalties()      <- add_penalty()     src/nnmf.cpp:224-240
+#include "../../include/nnlm_mi355x.h"
+#include "common.h"
+#include "k_errors.h"
+#include "k_gram.h"
+#include "k_prep.h"
+#include "k_sweep.h"
+#include "k_xprod.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_COUNT };
+static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors"};
+
+struct ProfRec {
+    int id;
+    hipEvent_t e0, e1;
+};
+
+struct nnlm_handle {
+    int device = 0;
+    int prec = NNLM_PREC_F32;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // problem
+    int n = 0, m = 0, npad = 0, mpad = 0;
+    void *A = nullptr;          // T [mpad][npad]
+    uint32_t *miss = nullptr;   // [mpad][npad/32]
+    bool any_missing = false;
+    double n_non_missing = 0.0, kl_const = 0.0;
+
+    // factors
+    int k = 0, NKQ = 0, KP = 0, KP8 = 0;
+    double *W64 = nullptr, *H64 = nullptr;        // [KP][npad], [KP][mpad]
+    void *Wop = nullptr, *Hop = nullptr;          // T [KP][npad] (aliases W64 in f64 mode), T [mpad][KP]
+    unsigned long long *Wmask = nullptr, *Hmask = nullptr; // per column bitmask, or null
+    bool has_wmask = false, has_hmask = false;
+
+    // workspaces
+    double *Cx = nullptr;
+    size_t Cx_elems = 0;
+    double *gslabs = nullptr, *Graw = nullptr;
+    double *partials = nullptr;
+    size_t partials_elems = 0;
+    double *scal = nullptr;              // 16 doubles of reduction results
+    unsigned long long *sweeps = nullptr;
+
+    // multi-GPU
+    int rank = 0, nranks = 1;
+    void *comm = nullptr;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    double prof_ms[P_COUNT] = {0};
+    long long prof_n[P_COUNT] = {0};
+};
+
+static int fail(nnlm_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                                              \
+    do {                                                                                                             \
+        hipError_t e__ = (call);                                                                                     \
+        if (e__ != hipSuccess) return fail(h, NNLM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+static size_t esize(const nnlm_handle *h) { return h->prec == NNLM_PREC_F64 ? 8 : 4; }
+
+// ---------------------------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+    nnlm_handle *h;
+    ProfRec r;
+    bool on;
+    ProfScope(nnlm_handle *h_, int id) : h(h_), on(h_->prof)
+    {
+        if (on) {
+            r.id = id;
+            hipEventCreate(&r.e0);
+            hipEventCreate(&r.e1);
+            hipEventRecord(r.e0, h->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            hipEventRecord(r.e1, h->stream);
+            h->recs.push_back(r);
+        }
+    }
+};
+
+static void prof_collect(nnlm_handle *h)
+{
+    if (h->recs.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            h->prof_ms[r.id] += ms;
+            h->prof_n[r.id] += 1;
+        }
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    h->recs.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnlm_abi_version(void) { return NNLM_ABI_VERSION; }
+
+extern "C" const char *nnlm_last_error(const nnlm_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+extern "C" unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace)
+{
+    if (trace < 1) trace = 1;
+    return (unsigned)std::ceil((double)max_iter / (double)trace) + 1; // src/nnmf.cpp:53-54
+}
+
+extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
+{
+    if (!out) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: out is NULL");
+    *out = nullptr;
+    if (precision != NNLM_PREC_F32 && precision != NNLM_PREC_F64) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: unknown precision %d", precision);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: no HIP device available (%s); libnnlm_mi355x has no CPU path", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: device %d out of range (0..%d)", device, ndev - 1);
+    HIPCHK(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    nnlm_handle *h = new nnlm_handle();
+    h->device = device;
+    h->prec = precision;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipStreamCreate failed");
+    }
+    if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, sizeof(unsigned long long)) != hipSuccess) {
+        delete h;
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
+    }
+    hipMemsetAsync(h->sweeps, 0, sizeof(unsigned long long), h->stream);
+    *out = h;
+    return NNLM_OK;
+}
+
+static void free_factors(nnlm_handle *h)
+{
+    if (h->Wop && h->Wop != (void *)h->W64) hipFree(h->Wop);
+    hipFree(h->W64);
+    hipFree(h->H64);
+    hipFree(h->Hop);
+    hipFree(h->Wmask);
+    hipFree(h->Hmask);
+    hipFree(h->Cx);
+    hipFree(h->gslabs);
+    hipFree(h->Graw);
+    h->W64 = h->H64 = nullptr;
+    h->Wop = h->Hop = nullptr;
+    h->Wmask = h->Hmask = nullptr;
+    h->Cx = h->gslabs = h->Graw = nullptr;
+    h->k = 0;
+}
+
+static void free_matrix(nnlm_handle *h)
+{
+    hipFree(h->A);
+    hipFree(h->miss);
+    hipFree(h->partials);
+    h->A = nullptr;
+    h->miss = nullptr;
+    h->partials = nullptr;
+    h->n = h->m = 0;
+}
+
+extern "C" void nnlm_destroy(nnlm_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    prof_collect(h);
+    free_factors(h);
+    free_matrix(h);
+    hipFree(h->scal);
+    hipFree(h->sweeps);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matrix upload
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_set_matrix: handle is NULL");
+    if (!A || n <= 0 || m <= 0) return fail(h, NNLM_ERR_ARG, "nnlm_set_matrix: A must be a non-empty n x m matrix (n=%d, m=%d)", n, m);
+    HIPCHK(h, hipSetDevice(h->device));
+    free_factors(h);
+    free_matrix(h);
+    h->n = n;
+    h->m = m;
+    h->npad = round_up_i(n, NNLM_PAD_N);
+    h->mpad = round_up_i(m, NNLM_PAD_M);
+    const size_t es = esize(h);
+    const size_t a_bytes = (size_t)h->npad * h->mpad * es;
+    const size_t miss_words = (size_t)h->mpad * (h->npad / 32);
+    HIPCHK(h, hipMalloc(&h->A, a_bytes + 4096));
+    HIPCHK(h, hipMalloc(&h->miss, miss_words * 4 + 64));
+    HIPCHK(h, hipMemsetAsync(h->A, 0, a_bytes + 4096, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->miss, 0, miss_words * 4 + 64, h->stream));
+    // partial-sum workspace shared by the prep / error / penalty reductions
+    const size_t err_blocks = (size_t)(h->npad / ERR_TILE) * (h->mpad / ERR_TILE);
+    const int gx = h->npad / PREP_BLOCK;
+    const size_t prep_blocks = (size_t)gx * PREP_GRID_Y;
+    h->partials_elems = 3 * (err_blocks > prep_blocks ? err_blocks : prep_blocks) + 64;
+    HIPCHK(h, hipMalloc(&h->partials, h->partials_elems * sizeof(double)));
+
+    // stream the caller's matrix through a bounded staging buffer (chunks of whole columns)
+    const size_t stage_bytes_max = (size_t)256 << 20;
+    int cols_per_chunk = (int)(stage_bytes_max / ((size_t)n * 8));
+    if (cols_per_chunk < 1) cols_per_chunk = 1;
+    if (cols_per_chunk > m) cols_per_chunk = m;
+    double *stage = nullptr;
+    HIPCHK(h, hipMalloc(&stage, (size_t)cols_per_chunk * n * 8));
+    std::vector<double> hp(2 * prep_blocks);
+    double cnt = 0.0, klc = 0.0;
+    int rc = NNLM_OK;
+    for (int j0 = 0; j0 < m && rc == NNLM_OK; j0 += cols_per_chunk) {
+        const int cols = (m - j0 < cols_per_chunk) ? m - j0 : cols_per_chunk;
+        hipError_t e = hipMemcpyAsync(stage, A + (size_t)j0 * n, (size_t)cols * n * 8, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { rc = fail(h, NNLM_ERR_HIP, "upload of A failed: %s", hipGetErrorString(e)); break; }
+        dim3 grid(gx, PREP_GRID_Y);
+        if (h->prec == NNLM_PREC_F64)
+            prep_convert_kernel<double><<<grid, PREP_BLOCK, 0, h->stream>>>(stage, n, cols, j0, (double *)h->A, h->npad, h->miss, h->partials);
+        else
+            prep_convert_kernel<float><<<grid, PREP_BLOCK, 0, h->stream>>>(stage, n, cols, j0, (float *)h->A, h->npad, h->miss, h->partials);
+        e = hipMemcpyAsync(hp.data(), h->partials, 2 * prep_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { rc = fail(h, NNLM_ERR_HIP, "prep pass failed: %s", hipGetErrorString(e)); break; }
+        for (size_t b = 0; b < prep_blocks; b++) {
+            cnt += hp[2 * b];
+            klc += hp[2 * b + 1];
+        }
+    }
+    hipFree(stage);
+    if (rc != NNLM_OK) return rc;
+    h->n_non_missing = cnt;
+    h->any_missing = cnt != (double)n * (double)m;
+    h->kl_const = klc / cnt; // mean((A+eps) log(A+eps) - A) over finite entries, src/nnmf.cpp:70,73
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_missing, double *kl_const)
+{
+    if (!h || !h->A) return fail(h, NNLM_ERR_ARG, "nnlm_matrix_info: no matrix set");
+    if (n_non_missing) *n_non_missing = h->n_non_missing;
+    if (any_missing) *any_missing = h->any_missing ? 1 : 0;
+    if (kl_const) *kl_const = h->kl_const;
+    return NNLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// factors
+// ---------------------------------------------------------------------------------------------
+static int split_plan(int tiles_x, int stages, int *S, int *sps)
+{
+    int s = (512 + tiles_x - 1) / tiles_x;
+    if (s < 1) s = 1;
+    if (s > stages) s = stages;
+    if (s < 1) s = 1;
+    int per = (stages + s - 1) / s;
+    if (per < 1) per = 1;
+    *S = (stages + per - 1) / per;
+    if (*S < 1) *S = 1;
+    *sps = per;
+    return 0;
+}
+
+struct HalfPlan {
+    int stage_begin, stage_end, S, sps, tiles_x;
+};
+
+// which = 1: H half-step (TN, contraction over i); which = 0: W half-step (NT, contraction over j)
+static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
+{
+    HalfPlan p;
+    int stages_total, tiles_x;
+    if (which == 1) {
+        const int CE = XPROD_ROWB / (int)esize(h);
+        stages_total = h->npad / CE;
+        tiles_x = h->mpad / XPROD_TN_BJ;
+    } else {
+        stages_total = h->mpad / XPROD_NT_ROWS;
+        const int BI = 64 * (16 / (int)esize(h));
+        tiles_x = h->npad / BI;
+    }
+    // this rank's slab of the contraction
+    const int per_rank = (stages_total + nranks - 1) / nranks;
+    p.stage_begin = rank * per_rank;
+    p.stage_end = p.stage_begin + per_rank;
+    if (p.stage_end > stages_total) p.stage_end = stages_total;
+    if (p.stage_begin > stages_total) p.stage_begin = stages_total;
+    int len = p.stage_end - p.stage_begin;
+    if (len < 1) len = 1;
+    split_plan(tiles_x, len, &p.S, &p.sps);
+    p.tiles_x = tiles_x;
+    return p;
+}
+
+static void pack_mask_cols(const int *mask, int k, int ncols, bool transposed_input, int ld_in, std::vector<unsigned long long> &out, int npadded)
+{
+    // transposed_input: mask is ncols x k column-major (Wm, n x k); else k x ncols column-major (Hm)
+    out.assign(npadded, 0ull);
+    for (int c = 0; c < ncols; c++) {
+        unsigned long long w = 0;
+        for (int q = 0; q < k; q++) {
+            const int v = transposed_input ? mask[(size_t)q * ld_in + c] : mask[(size_t)c * ld_in + q];
+            if (v != 0) w |= (1ull << q);
+        }
+        out[c] = w;
+    }
+}
+
+extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, const double *H, const int *Wm, const int *Hm)
+{
+    if (!h || !h->A) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: set the matrix first");
+    const int k = (int)k_;
+    if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
+    if (k > NNLM_KQ_MAX) return fail(h, NNLM_ERR_UNSUPPORTED, "nnlm_set_factors: rank k=%d > %d is not supported by this build", k, NNLM_KQ_MAX);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (k != h->k) {
+        free_factors(h);
+        h->k = k;
+        h->NKQ = (k + 15) / 16;
+        h->KP = 16 * h->NKQ;
+        h->KP8 = round_up_i(k, 8);
+        const size_t es = esize(h);
+        HIPCHK(h, hipMalloc(&h->W64, (size_t)h->KP * h->npad * 8));
+        HIPCHK(h, hipMalloc(&h->H64, (size_t)h->KP * h->mpad * 8));
+        if (h->prec == NNLM_PREC_F64) h->Wop = h->W64;
+        else HIPCHK(h, hipMalloc(&h->Wop, (size_t)h->KP * h->npad * es));
+        HIPCHK(h, hipMalloc(&h->Hop, (size_t)h->mpad * h->KP * es + 4096));
+        HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * 8));
+        HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * 8));
+        // split-K slabs: sized for the worst case over ranks (nranks = 1 gives the largest S)
+        const HalfPlan ph = plan_half(h, 1, 0, 1), pw = plan_half(h, 0, 0, 1);
+        const size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
+        h->Cx_elems = eh > ew ? eh : ew;
+        HIPCHK(h, hipMalloc(&h->Cx, h->Cx_elems * 8));
+        const int gb = (h->npad > h->mpad ? h->npad : h->mpad) / GRAM_COLS_PER_BLOCK + 1;
+        HIPCHK(h, hipMalloc(&h->gslabs, (size_t)gb * h->KP * h->KP * 8));
+        HIPCHK(h, hipMalloc(&h->Graw, (size_t)h->KP * h->KP * 8));
+    }
+    const int KP = h->KP, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
+    // host-side repack into the padded resident layouts (k*(n+m) elements: negligible)
+    std::vector<double> w64((size_t)KP * npad, 0.0), h64((size_t)KP * mpad, 0.0);
+    if (W)
+        for (int q = 0; q < k; q++)
+            for (int i = 0; i < n; i++) w64[(size_t)q * npad + i] = W[(size_t)q * n + i]; // W is n x k column-major
+    if (H)
+        for (int j = 0; j < m; j++)
+            for (int q = 0; q < k; q++) h64[(size_t)q * mpad + j] = H[(size_t)j * k + q]; // H is k x m column-major
+    HIPCHK(h, hipMemcpy(h->W64, w64.data(), w64.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->H64, h64.data(), h64.size() * 8, hipMemcpyHostToDevice));
+    if (h->prec == NNLM_PREC_F64) {
+        std::vector<double> hop((size_t)mpad * KP, 0.0);
+        for (int j = 0; j < m; j++)
+            for (int q = 0; q < k; q++) hop[(size_t)j * KP + q] = h64[(size_t)q * mpad + j];
+        HIPCHK(h, hipMemcpy(h->Hop, hop.data(), hop.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> wop((size_t)KP * npad), hop((size_t)mpad * KP, 0.f);
+        for (size_t e = 0; e < wop.size(); e++) wop[e] = (float)w64[e];
+        for (int j = 0; j < m; j++)
+            for (int q = 0; q < k; q++) hop[(size_t)j * KP + q] = (float)h64[(size_t)q * mpad + j];
+        HIPCHK(h, hipMemcpy(h->Wop, wop.data(), wop.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->Hop, hop.data(), hop.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<unsigned long long> mk;
+    h->has_wmask = Wm != nullptr;
+    h->has_hmask = Hm != nullptr;
+    if (Wm) {
+        pack_mask_cols(Wm, k, n, true, n, mk, npad);
+        HIPCHK(h, hipMemcpy(h->Wmask, mk.data(), (size_t)npad * 8, hipMemcpyHostToDevice));
+    }
+    if (Hm) {
+        pack_mask_cols(Hm, k, m, false, k, mk, mpad);
+        HIPCHK(h, hipMemcpy(h->Hmask, mk.data(), (size_t)mpad * 8, hipMemcpyHostToDevice));
+    }
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_get_factors(nnlm_handle *h, double *W, double *H)
+{
+    if (!h || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_get_factors: no factors set");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int k = h->k, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
+    if (W) {
+        std::vector<double> w64((size_t)h->KP * npad);
+        HIPCHK(h, hipMemcpy(w64.data(), h->W64, w64.size() * 8, hipMemcpyDeviceToHost));
+        for (int q = 0; q < k; q++) memcpy(W + (size_t)q * n, &w64[(size_t)q * npad], (size_t)n * 8);
+    }
+    if (H) {
+        std::vector<double> h64((size_t)h->KP * mpad);
+        HIPCHK(h, hipMemcpy(h64.data(), h->H64, h64.size() * 8, hipMemcpyDeviceToHost));
+        for (int j = 0; j < m; j++)
+            for (int q = 0; q < k; q++) H[(size_t)j * k + q] = h64[(size_t)q * mpad + j];
+    }
+    return NNLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// half-step
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NKQ>
+static void launch_xprod(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    const int KP = 16 * NKQ;
+    if (which == 1) {
+        dim3 grid(p.tiles_x, p.S);
+        const int lds = xprod_tn_lds_bytes(KP);
+        hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        xprod_tn_kernel<T, NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Wop, h->npad, h->Cx, h->mpad,
+                                                                          (size_t)KP * h->mpad, p.stage_begin, p.stage_end, p.sps);
+    } else {
+        dim3 grid(p.tiles_x, p.S);
+        const int lds = xprod_nt_lds_bytes<T>(KP);
+        hipFuncSetAttribute((const void *)xprod_nt_kernel<T, NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        xprod_nt_kernel<T, NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Hop, h->Cx, h->npad,
+                                                                          (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
+    }
+}
+
+template <typename T>
+static void launch_xprod_nkq(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    switch (h->NKQ) {
+    case 1: launch_xprod<T, 1>(h, which, p); break;
+    case 2: launch_xprod<T, 2>(h, which, p); break;
+    case 3: launch_xprod<T, 3>(h, which, p); break;
+    default: launch_xprod<T, 4>(h, which, p); break;
+    }
+}
+
+static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, int c_end, int *nslabs)
+{
+    int nb = (c_end - c_begin + GRAM_COLS_PER_BLOCK - 1) / GRAM_COLS_PER_BLOCK;
+    if (nb < 1) nb = 1;
+    switch (h->NKQ) {
+    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    }
+    const int KP = h->KP;
+    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
+    *nslabs = nb;
+}
+
+template <int NCH>
+static void launch_sweep_m(int method, const SweepArgs &a, hipStream_t s)
+{
+    const int nb = (a.ncols + 63) / 64;
+    if (method == 1) sweep_ls_kernel<NCH, 1><<<nb, 64, 0, s>>>(a);
+    else sweep_ls_kernel<NCH, 2><<<nb, 64, 0, s>>>(a);
+}
+
+static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
+{
+    switch (h->KP8 / 8) {
+    case 1: launch_sweep_m<1>(method, a, h->stream); break;
+    case 2: launch_sweep_m<2>(method, a, h->stream); break;
+    case 3: launch_sweep_m<3>(method, a, h->stream); break;
+    case 4: launch_sweep_m<4>(method, a, h->stream); break;
+    case 5: launch_sweep_m<5>(method, a, h->stream); break;
+    case 6: launch_sweep_m<6>(method, a, h->stream); break;
+    case 7: launch_sweep_m<7>(method, a, h->stream); break;
+    default: launch_sweep_m<8>(method, a, h->stream); break;
+    }
+}
+
+static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method)
+{
+    if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
+    if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
+    if (method >= 3) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods (3, 4) are not implemented in this build yet");
+    if (h->any_missing) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not implemented in this build yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    const HalfPlan p = plan_half(h, which, h->rank, h->nranks);
+    // 1. cross product slabs
+    {
+        ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
+        if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
+        else launch_xprod_nkq<float>(h, which, p);
+    }
+    // 2. Gram of the fixed factor over this rank's contraction slab
+    int gslabs = 0;
+    {
+        ProfScope ps(h, P_GRAM);
+        const int CE = (which == 1) ? XPROD_ROWB / (int)esize(h) : XPROD_NT_ROWS;
+        int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
+        const int lim = (which == 1) ? h->n : h->m;
+        if (c1 > lim) c1 = lim;
+        if (c0 > c1) c0 = c1;
+        if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs);
+        else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs);
+    }
+    // (multi-GPU: all-reduce of [Graw | Cx] goes here)
+    // 3. per-column solve
+    {
+        ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
+        SweepArgs a;
+        a.Graw = h->Graw;
+        a.KPg = h->KP;
+        a.Cx = h->Cx;
+        a.nslabs = p.S;
+        a.k = h->k;
+        a.r0 = reg[0];
+        a.r1 = reg[1];
+        a.r2 = reg[2];
+        a.max_iter = inner_max_iter;
+        a.rel_tol = inner_rel_tol;
+        a.sweeps = h->sweeps;
+        if (which == 1) {
+            a.X = h->H64;
+            a.ldx = h->mpad;
+            a.ldc = h->mpad;
+            a.slab_stride = (size_t)h->KP * h->mpad;
+            a.ncols = h->m;
+            a.mask = h->has_hmask ? h->Hmask : nullptr;
+            a.op = h->Hop;
+            a.op_mode = 2;
+            a.op_ld = h->KP;
+        } else {
+            a.X = h->W64;
+            a.ldx = h->npad;
+            a.ldc = h->npad;
+            a.slab_stride = (size_t)h->KP * h->npad;
+            a.ncols = h->n;
+            a.mask = h->has_wmask ? h->Wmask : nullptr;
+            a.op = h->Wop;
+            a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1;
+            a.op_ld = h->npad;
+        }
+        a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
+        launch_sweep(h, method, a);
+    }
+    HIPCHK(h, hipGetLastError());
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method)
+{
+    if (which != 0 && which != 1) return fail(h, NNLM_ERR_ARG, "nnlm_half_step: which must be 0 (W) or 1 (H)");
+    if (!reg) return fail(h, NNLM_ERR_ARG, "nnlm_half_step: reg is NULL");
+    return half_step(h, which, reg, inner_max_iter, inner_rel_tol, method);
+}
+
+extern "C" int nnlm_iterate(nnlm_handle *h, unsigned n_iter, const double alpha[3], const double beta[3], unsigned inner_max_iter,
+                            double inner_rel_tol, int method)
+{
+    for (unsigned i = 0; i < n_iter; i++) {
+        int rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method); // update W, src/nnmf.cpp:131
+        if (rc != NNLM_OK) return rc;
+        rc = half_step(h, 1, beta, inner_max_iter, inner_rel_tol, method); // update H, src/nnmf.cpp:133
+        if (rc != NNLM_OK) return rc;
+    }
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_take_sweeps(nnlm_handle *h, long long *sweeps, int reset)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_take_sweeps: handle is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->sweeps, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    if (reset) HIPCHK(h, hipMemsetAsync(h->sweeps, 0, sizeof v, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sweeps) *sweeps = (long long)v;
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_sync(nnlm_handle *h)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_sync: handle is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NNLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// error block
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double pen[6])
+{
+    if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_errors: matrix and factors must be set first");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int k4 = round_up_i(h->k, 4);
+    dim3 grid(h->npad / ERR_TILE, h->mpad / ERR_TILE);
+    const size_t nb = (size_t)grid.x * grid.y;
+    {
+        ProfScope ps(h, P_ERRORS);
+        const uint32_t *miss = h->any_missing ? h->miss : nullptr;
+        if (h->prec == NNLM_PREC_F64)
+            errors_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
+        else
+            errors_kernel<float><<<grid, 256, 0, h->stream>>>((const float *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
+        reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, nb, 2, h->scal);
+    }
+    const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
+    penalty_kernel<<<nbw, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->partials);
+    reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
+    penalty_kernel<<<nbh, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, h->partials);
+    reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
+    double out[8];
+    HIPCHK(h, hipMemcpyAsync(out, h->scal, sizeof out, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (mse) *mse = out[0] / h->n_non_missing;
+    if (mkl_var) *mkl_var = out[1] / h->n_non_missing;
+    if (pen)
+        for (int i = 0; i < 6; i++) pen[i] = out[2 + i];
+    return NNLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnlm_profile_enable(nnlm_handle *h, int on)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "handle is NULL");
+    prof_collect(h);
+    h->prof = on != 0;
+    return NNLM_OK;
+}
+extern "C" int nnlm_profile_reset(nnlm_handle *h)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "handle is NULL");
+    prof_collect(h);
+    for (int i = 0; i < P_COUNT; i++) {
+        h->prof_ms[i] = 0;
+        h->prof_n[i] = 0;
+    }
+    return NNLM_OK;
+}
+extern "C" int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_ms, long long *launches)
+{
+    if (!h || !name) return fail(h, NNLM_ERR_ARG, "nnlm_profile_get: bad arguments");
+    prof_collect(h);
+    for (int i = 0; i < P_COUNT; i++)
+        if (strcmp(name, kProfNames[i]) == 0) {
+            if (total_ms) *total_ms = h->prof_ms[i];
+            if (launches) *launches = h->prof_n[i];
+            return NNLM_OK;
+        }
+    return fail(h, NNLM_ERR_ARG, "nnlm_profile_get: unknown kernel class '%s'", name);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU (filled in by comm.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES])
+{
+    (void)id;
+    return fail(nullptr, NNLM_ERR_UNSUPPORTED, "RCCL path not built yet");
+}
+extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES], int rank, int nranks)
+{
+    (void)id;
+    (void)rank;
+    (void)nranks;
+    return fail(h, NNLM_ERR_UNSUPPORTED, "RCCL path not built yet");
+}
+extern "C" int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "handle is NULL");
+    if (rank) *rank = h->rank;
+    if (nranks) *nranks = h->nranks;
+    return NNLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-shot drivers
+// ---------------------------------------------------------------------------------------------
+static int env_precision()
+{
+    const char *e = getenv("NNLM_PRECISION");
+    if (e && (strcmp(e, "f64") == 0 || strcmp(e, "fp64") == 0 || strcmp(e, "1") == 0)) return NNLM_PREC_F64;
+    return NNLM_PREC_F32;
+}
+static int env_device()
+{
+    const char *e = getenv("NNLM_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+struct Lcg {
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    double next()
+    {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(s >> 11) * (1.0 / 9007199254740992.0);
+    }
+};
+
+static void cb_print(const nnlm_callbacks *cb, const char *fmt, ...)
+{
+    if (!cb || !cb->print) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    cb->print(cb->ctx, buf);
+}
+
+// add_penalty, src/nnmf.cpp:224-240 (same order of the six terms)
+static double penalties(double terr, const double pen[6], double N, const double alpha[3], const double beta[3])
+{
+    if (alpha[0] != alpha[1]) terr += 0.5 * (alpha[0] - alpha[1]) * pen[0] / N;
+    if (beta[0] != beta[1]) terr += 0.5 * (beta[0] - beta[1]) * pen[3] / N;
+    if (alpha[1] != 0) terr += 0.5 * alpha[1] * pen[1] / N;
+    if (beta[1] != 0) terr += 0.5 * beta[1] * pen[4] / N;
+    if (alpha[2] != 0) terr += alpha[2] * pen[2] / N;
+    if (beta[2] != 0) terr += beta[2] * pen[5] / N;
+    return terr;
+}
+
+extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const double *W_init, const double *H_init, const int *Wm,
+                           const int *Hm, const double alpha[3], const double beta[3], unsigned max_iter, double rel_tol,
+                           int n_threads, int verbose, int show_warning, unsigned inner_max_iter, double inner_rel_tol,
+                           int method, unsigned trace, double *W_out, double *H_out, double *mse_error, double *mkl_error,
+                           double *target_error, double *average_epoch, int *n_trace, unsigned *n_iteration, int *warned,
+                           const nnlm_callbacks *cb)
+{
+    (void)n_threads;
+    if (!A || !alpha || !beta || !W_out || !H_out || !mse_error || !mkl_error || !target_error || !average_epoch || !n_trace ||
+        !n_iteration || !warned)
+        return fail(nullptr, NNLM_ERR_ARG, "nnlm_c_nnmf: NULL argument");
+    if (k < 1) return fail(nullptr, NNLM_ERR_ARG, "nnlm_c_nnmf: k must be >= 1");
+    nnlm_handle *h = nullptr;
+    int rc = nnlm_create(&h, env_device(), env_precision());
+    if (rc != NNLM_OK) return rc;
+    struct Guard {
+        nnlm_handle *h;
+        ~Guard() { nnlm_destroy(h); }
+    } guard{h};
+#define CHK(x)                                   \
+    do {                                         \
+        rc = (x);                                \
+        if (rc != NNLM_OK) {                     \
+            g_last_error = h->err;               \
+            return rc;                           \
+        }                                        \
+    } while (0)
+
+    if (trace < 1) trace = 1; // src/nnmf.cpp:53
+    const unsigned err_len = nnlm_trace_capacity(max_iter, trace);
+    CHK(nnlm_set_matrix(h, A, n, m));
+    const double N = h->n_non_missing;
+    for (unsigned e = 0; e < err_len; e++) mkl_error[e] = h->kl_const; // src/nnmf.cpp:70,73
+
+    // default init, src/nnmf.cpp:82-98: W.randu(k,n)*0.01 drawn column-major, W first, masked entries zeroed
+    std::vector<double> Wi, Hi;
+    Lcg lcg;
+    auto draw = [&]() { return (cb && cb->unif_rand) ? cb->unif_rand(cb->ctx) : lcg.next(); };
+    if (!W_init) {
+        Wi.resize((size_t)n * k);
+        for (int i = 0; i < n; i++)
+            for (unsigned q = 0; q < k; q++) {
+                double v = draw() * 0.01;
+                if (Wm && Wm[(size_t)q * n + i] > 0) v = 0.0;
+                Wi[(size_t)q * n + i] = v;
+            }
+        W_init = Wi.data();
+    }
+    if (!H_init) {
+        Hi.resize((size_t)k * m);
+        for (size_t e = 0; e < (size_t)k * m; e++) {
+            double v = draw() * 0.01;
+            if (Hm && Hm[e] > 0) v = 0.0;
+            Hi[e] = v;
+        }
+        H_init = Hi.data();
+    }
+    CHK(nnlm_set_factors(h, k, W_init, H_init, Wm, Hm));
+
+    if (verbose == 2) { // src/nnmf.cpp:100-104
+        cb_print(cb, "\n%10s | %10s | %10s | %10s | %10s\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
+        cb_print(cb, "--------------------------------------------------------------\n");
+    }
+
+    double rel_err = rel_tol + 1, terr_last = 1e99;
+    unsigned i = 0, i_e = 0;
+    auto error_block = [&](unsigned it) -> int {
+        double mse, kl, pen[6];
+        long long raw = 0;
+        int r = nnlm_errors(h, &mse, &kl, pen);
+        if (r != NNLM_OK) return r;
+        r = nnlm_take_sweeps(h, &raw, 1); // total_raw_iter, reset to 0 (src/nnmf.cpp:158)
+        if (r != NNLM_OK) return r;
+        mse_error[i_e] = mse;
+        mkl_error[i_e] += kl;
+        average_epoch[i_e] = (double)raw / (double)(n + m); // src/nnmf.cpp:145
+        double t = (method < 3) ? 0.5 * mse_error[i_e] : mkl_error[i_e];
+        t = penalties(t, pen, N, alpha, beta);
+        target_error[i_e] = t;
+        rel_err = 2 * (terr_last - t) / (terr_last + t + NNLM_TINY); // src/nnmf.cpp:153
+        terr_last = t;
+        if (verbose == 2) cb_print(cb, "%10d | %10.4f | %10.4f | %10.4f | %10.g\n", it + 1, mse_error[i_e], mkl_error[i_e], t, rel_err);
+        ++i_e;
+        return NNLM_OK;
+    };
+
+    for (; i < max_iter && std::fabs(rel_err) > rel_tol; i++) { // src/nnmf.cpp:109
+        if (cb && cb->check_interrupt && cb->check_interrupt(cb->ctx)) { // src/nnmf.cpp:111
+            g_last_error = "interrupted";
+            return NNLM_ERR_INTERRUPT;
+        }
+        if (verbose == 1 && cb && cb->progress) cb->progress(cb->ctx, i + 1, max_iter); // src/nnmf.cpp:112
+        CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method));
+        CHK(half_step(h, 1, beta, inner_max_iter, inner_rel_tol, method));
+        if (i % trace == 0) CHK(error_block(i));
+    }
+    if ((unsigned)(i - 1) % trace != 0) CHK(error_block(i)); // src/nnmf.cpp:164 (unsigned arithmetic)
+
+    if (verbose == 2) { // src/nnmf.cpp:194-198
+        cb_print(cb, "--------------------------------------------------------------\n");
+        cb_print(cb, "%10s | %10s | %10s | %10s | %10s\n\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
+    }
+    *n_trace = (int)i_e;
+    *n_iteration = i;
+    *warned = (show_warning && rel_err > rel_tol) ? 1 : 0; // src/nnmf.cpp:208
+    if (*warned && cb && cb->warning) cb->warning(cb->ctx, "Target tolerance not reached. Try a larger max.iter.");
+    CHK(nnlm_get_factors(h, W_out, H_out));
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_c_nnlm(const double *x, const double *y, int n, int p, int q, const double alpha[3], const int *mask,
+                           const double *beta0, unsigned max_iter, double rel_tol, int n_threads, int method, double *coefficient,
+                           int *n_iteration, const nnlm_callbacks *cb)
+{
+    (void)n_threads;
+    if (!x || !y || !alpha || !coefficient || !n_iteration) return fail(nullptr, NNLM_ERR_ARG, "nnlm_c_nnlm: NULL argument");
+    if (n < 1 || p < 1 || q < 1) return fail(nullptr, NNLM_ERR_ARG, "nnlm_c_nnlm: empty x or y");
+    nnlm_handle *h = nullptr;
+    int rc = nnlm_create(&h, env_device(), env_precision());
+    if (rc != NNLM_OK) return rc;
+    struct Guard {
+        nnlm_handle *h;
+        ~Guard() { nnlm_destroy(h); }
+    } guard{h};
+    // y plays A (n x q), x plays W (n x p), beta plays H (p x q): one H half-step, src/nnlm.cpp:44-47
+    CHK(nnlm_set_matrix(h, y, n, q));
+    std::vector<double> b0;
+    if (!beta0) { // beta.randu(), src/nnlm.cpp:38-39
+        b0.resize((size_t)p * q);
+        Lcg lcg;
+        for (auto &v : b0) v = (cb && cb->unif_rand) ? cb->unif_rand(cb->ctx) : lcg.next();
+        beta0 = b0.data();
+    }
+    CHK(nnlm_set_factors(h, (unsigned)p, x, beta0, nullptr, mask));
+    CHK(half_step(h, 1, alpha, max_iter, rel_tol, method));
+    long long raw = 0;
+    CHK(nnlm_take_sweeps(h, &raw, 1));
+    *n_iteration = (int)raw;
+    CHK(nnlm_get_factors(h, nullptr, coefficient));
+    return NNLM_OK;
+#undef CHK
+}
