@@ -150,9 +150,15 @@ int nnlm_profile_reset(nnlm_handle *h);
 #define NNLM_COMM_ID_BYTES 128
 int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */
 int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES], int rank, int nranks);
-/* Shard description without a communicator (virtual ranks, single-device tests): the handle
- * computes only rank `rank`'s slab of an `nranks`-way split and leaves the partial sums in place. */
+/* id == NULL makes a "virtual rank": the handle only computes rank's slab of an nranks-way split and leaves the
+ * partial sums un-reduced (used with nnlm_debug_partial to test the shard arithmetic on one device). */
 int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks);
+/* Contraction range [begin, end) owned by `rank` of `nranks`: rows i of A for the H half-step (which = 1), columns j
+ * for the W half-step (which = 0).  Pure function of the sizes (no device needed). */
+int nnlm_shard_range(int n, int m, int precision, int which, int rank, int nranks, int *begin, int *end);
+/* Test hook: partial [Gram k x k | cross product k x cols] of this (virtual) rank's slab, column-major, before the
+ * all-reduce and before the regularisation edits of src/update_with_missing.cpp:20-24. */
+int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ EXPORTS = [
     "nnlm_abi_version", "nnlm_set_matrix", "nnlm_matrix_info", "nnlm_set_factors", "nnlm_get_factors",
     "nnlm_half_step", "nnlm_iterate", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
+    "nnlm_shard_range", "nnlm_debug_partial",
 ]
 
 
@@ -103,6 +104,10 @@ def load():
     lib.nnlm_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     lib.nnlm_comm_info.restype = C.c_int
     lib.nnlm_comm_info.argtypes = [vp, ip, ip]
+    lib.nnlm_shard_range.restype = C.c_int
+    lib.nnlm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
+    lib.nnlm_debug_partial.restype = C.c_int
+    lib.nnlm_debug_partial.argtypes = [vp, C.c_int, dp, dp]
     _lib = lib
     return lib
 
@@ -300,14 +305,29 @@ class Handle:
         self._ck(self._lib.nnlm_profile_get(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, int(cnt.value)
 
-    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
-        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+    def comm_init(self, unique_id, rank: int, nranks: int):
+        """unique_id=None -> virtual rank (no communicator; partial sums stay un-reduced)."""
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES) if unique_id is not None else None
         self._ck(self._lib.nnlm_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def debug_partial(self, which):
+        cols = self.m if which == 1 else self.n
+        G = np.zeros((self.k, self.k), order="F")
+        Cm = np.zeros((self.k, cols), order="F")
+        self._ck(self._lib.nnlm_debug_partial(self._h, int(which), _dp(G), _dp(Cm)))
+        return np.ascontiguousarray(G), np.ascontiguousarray(Cm)
 
     def comm_info(self):
         r, n = C.c_int(0), C.c_int(0)
         self._ck(self._lib.nnlm_comm_info(self._h, C.byref(r), C.byref(n)))
         return r.value, n.value
+
+
+def shard_range(n, m, precision, which, rank, nranks):
+    """Contraction range [begin, end) of `rank` (pure host function of the C ABI, works without a GPU)."""
+    b, e = C.c_int(0), C.c_int(0)
+    _check(load().nnlm_shard_range(int(n), int(m), int(precision), int(which), int(rank), int(nranks), C.byref(b), C.byref(e)))
+    return b.value, e.value
 
 
 def comm_unique_id() -> bytes:

@@ -93,3 +93,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     for (int i = 0; i < nslabs; i++) s += slabs[(size_t)i * KP * KP + src];
     G[idx] = s;
 }
+
+// out[e] = sum_s slabs[s][e] (fixed order): folds the split-K slabs of the cross product into the contiguous
+// buffer that one RCCL all-reduce sums over ranks.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restrict__ slabs, int nslabs, size_t cnt,
+                                                          double *__restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cnt) return;
+    double s = 0.0;
+    for (int i = 0; i < nslabs; i++) s += slabs[(size_t)i * cnt + e];
+    out[e] = s;
+}

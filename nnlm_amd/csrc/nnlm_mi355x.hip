@@ -17,6 +17,9 @@
 #include "k_sweep.h"
 #include "k_xprod.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,7 +61,8 @@ struct nnlm_handle {
     // workspaces
     double *Cx = nullptr;
     size_t Cx_elems = 0;
-    double *gslabs = nullptr, *Graw = nullptr;
+    double *gslabs = nullptr, *Graw = nullptr; // Graw = head of red
+    double *red = nullptr;               // [KP*KP | KP*max(npad,mpad)]: the buffer one all-reduce sums
     double *partials = nullptr;
     size_t partials_elems = 0;
     double *scal = nullptr;              // 16 doubles of reduction results
@@ -136,6 +140,35 @@ static void prof_collect(nnlm_handle *h)
     h->recs.clear();
 }
 
+// RCCL entry points, resolved lazily with dlopen (single-GPU runs never touch librccl)
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.lib) return NNLM_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(nullptr, NNLM_ERR_COMM, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(nullptr, NNLM_ERR_COMM, "librccl lacks a required symbol");
+    g_rccl.lib = lib;
+    return NNLM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------------------------
@@ -190,7 +223,8 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Hmask);
     hipFree(h->Cx);
     hipFree(h->gslabs);
-    hipFree(h->Graw);
+    hipFree(h->red);
+    h->red = nullptr;
     h->W64 = h->H64 = nullptr;
     h->Wop = h->Hop = nullptr;
     h->Wmask = h->Hmask = nullptr;
@@ -386,7 +420,8 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         HIPCHK(h, hipMalloc(&h->Cx, h->Cx_elems * 8));
         const int gb = (h->npad > h->mpad ? h->npad : h->mpad) / GRAM_COLS_PER_BLOCK + 1;
         HIPCHK(h, hipMalloc(&h->gslabs, (size_t)gb * h->KP * h->KP * 8));
-        HIPCHK(h, hipMalloc(&h->Graw, (size_t)h->KP * h->KP * 8));
+        HIPCHK(h, hipMalloc(&h->red, ((size_t)h->KP * h->KP + (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad)) * 8));
+        h->Graw = h->red;
     }
     const int KP = h->KP, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
     // host-side repack into the padded resident layouts (k*(n+m) elements: negligible)
@@ -516,7 +551,8 @@ static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
     }
 }
 
-static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method)
+static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
+                     bool partial_only = false)
 {
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
@@ -542,15 +578,26 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs);
         else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs);
     }
-    // (multi-GPU: all-reduce of [Graw | Cx] goes here)
+    // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer and sum it over ranks: ONE all-reduce
+    const bool sharded = h->nranks > 1;
+    if (sharded) {
+        const int ld = (which == 1) ? h->mpad : h->npad;
+        const size_t cnt = (size_t)h->KP * ld;
+        slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, p.S, cnt, h->red + (size_t)h->KP * h->KP);
+        if (h->comm) {
+            ncclResult_t r = g_rccl.AllReduce(h->red, h->red, (size_t)h->KP * h->KP + cnt, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
+            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        }
+        if (partial_only) return NNLM_OK;
+    }
     // 3. per-column solve
     {
         ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
         SweepArgs a;
         a.Graw = h->Graw;
         a.KPg = h->KP;
-        a.Cx = h->Cx;
-        a.nslabs = p.S;
+        a.Cx = sharded ? h->red + (size_t)h->KP * h->KP : h->Cx;
+        a.nslabs = sharded ? 1 : p.S;
         a.k = h->k;
         a.r0 = reg[0];
         a.r1 = reg[1];
@@ -591,6 +638,37 @@ extern "C" int nnlm_half_step(nnlm_handle *h, int which, const double reg[3], un
     if (which != 0 && which != 1) return fail(h, NNLM_ERR_ARG, "nnlm_half_step: which must be 0 (W) or 1 (H)");
     if (!reg) return fail(h, NNLM_ERR_ARG, "nnlm_half_step: reg is NULL");
     return half_step(h, which, reg, inner_max_iter, inner_rel_tol, method);
+}
+
+// Test hook: run the cross-product + Gram stage of a half-step for this (virtual) rank and return the partial
+// [G (k x k) | C (k x cols)] sums, column-major, before any all-reduce and before the regularisation edits.
+extern "C" int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out)
+{
+    if (!h || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_debug_partial: matrix and factors must be set first");
+    if (which != 0 && which != 1) return fail(h, NNLM_ERR_ARG, "nnlm_debug_partial: which must be 0 or 1");
+    const double z[3] = {0, 0, 0};
+    // sharded handles return right after the slab fold; a 1-rank handle runs a zero-sweep solve (a no-op on the
+    // factors) and its slabs are folded here
+    int rc = half_step(h, which, z, 0, 0.0, 1, true);
+    if (rc != NNLM_OK) return rc;
+    const int ld = (which == 1) ? h->mpad : h->npad;
+    if (h->nranks == 1) {
+        const HalfPlan q = plan_half(h, which, 0, 1);
+        const size_t cnt = (size_t)h->KP * ld;
+        slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, q.S, cnt, h->red + (size_t)h->KP * h->KP);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int KP = h->KP, k = h->k;
+    const int cols = (which == 1) ? h->m : h->n;
+    std::vector<double> buf((size_t)KP * KP + (size_t)KP * ld);
+    HIPCHK(h, hipMemcpy(buf.data(), h->red, buf.size() * 8, hipMemcpyDeviceToHost));
+    if (G_out)
+        for (int r = 0; r < k; r++)
+            for (int q2 = 0; q2 < k; q2++) G_out[(size_t)r * k + q2] = buf[(size_t)q2 * KP + r];
+    if (C_out)
+        for (int c = 0; c < cols; c++)
+            for (int q2 = 0; q2 < k; q2++) C_out[(size_t)c * k + q2] = buf[(size_t)KP * KP + (size_t)q2 * ld + c];
+    return NNLM_OK;
 }
 
 extern "C" int nnlm_iterate(nnlm_handle *h, unsigned n_iter, const double alpha[3], const double beta[3], unsigned inner_max_iter,
@@ -694,25 +772,75 @@ extern "C" int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_
 }
 
 // ---------------------------------------------------------------------------------------------
-// multi-GPU (filled in by comm.h)
+// multi-GPU: RCCL, loaded lazily (single-GPU runs never touch librccl)
 // ---------------------------------------------------------------------------------------------
 extern "C" int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES])
 {
-    (void)id;
-    return fail(nullptr, NNLM_ERR_UNSUPPORTED, "RCCL path not built yet");
+    static_assert(NNLM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id) return fail(nullptr, NNLM_ERR_ARG, "nnlm_comm_unique_id: id is NULL");
+    int rc = rccl_load();
+    if (rc != NNLM_OK) return rc;
+    ncclUniqueId u;
+    ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, NNLM_ERR_COMM, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    memcpy(id, u.internal, NNLM_COMM_ID_BYTES);
+    return NNLM_OK;
 }
+
+// id == NULL: "virtual rank" -- the handle computes rank's slab of an nranks-way split and leaves the partial
+// [G | C] buffer un-reduced (single-device tests of the shard arithmetic, see nnlm_debug_partial).
 extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES], int rank, int nranks)
 {
-    (void)id;
-    (void)rank;
-    (void)nranks;
-    return fail(h, NNLM_ERR_UNSUPPORTED, "RCCL path not built yet");
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_comm_init: handle is NULL");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, NNLM_ERR_ARG, "nnlm_comm_init: bad rank %d of %d", rank, nranks);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->comm) {
+        g_rccl.CommDestroy((ncclComm_t)h->comm);
+        h->comm = nullptr;
+    }
+    h->rank = rank;
+    h->nranks = nranks;
+    if (!id || nranks == 1) return NNLM_OK;
+    int rc = rccl_load();
+    if (rc != NNLM_OK) return rc;
+    ncclUniqueId u;
+    memcpy(u.internal, id, NNLM_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    h->comm = comm;
+    return NNLM_OK;
 }
+
 extern "C" int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks)
 {
     if (!h) return fail(nullptr, NNLM_ERR_ARG, "handle is NULL");
     if (rank) *rank = h->rank;
     if (nranks) *nranks = h->nranks;
+    return NNLM_OK;
+}
+
+// Contraction range [begin, end) (in rows i of A for which = 1, columns j for which = 0) that rank `rank` of
+// `nranks` owns.  Pure function of the sizes: the partition is stage-granular (a stage = 256 bytes of an A column for
+// the TN kernel, 32 columns for the NT kernel), clipped to the true extent.
+extern "C" int nnlm_shard_range(int n, int m, int precision, int which, int rank, int nranks, int *begin, int *end)
+{
+    if (n < 1 || m < 1 || nranks < 1 || rank < 0 || rank >= nranks || (which != 0 && which != 1) || !begin || !end)
+        return fail(nullptr, NNLM_ERR_ARG, "nnlm_shard_range: bad arguments");
+    nnlm_handle t;
+    t.prec = precision;
+    t.n = n;
+    t.m = m;
+    t.npad = round_up_i(n, NNLM_PAD_N);
+    t.mpad = round_up_i(m, NNLM_PAD_M);
+    const HalfPlan p = plan_half(&t, which, rank, nranks);
+    const int CE = (which == 1) ? XPROD_ROWB / (int)esize(&t) : XPROD_NT_ROWS;
+    const int lim = (which == 1) ? n : m;
+    int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
+    if (c1 > lim) c1 = lim;
+    if (c0 > c1) c0 = c1;
+    *begin = c0;
+    *end = c1;
     return NNLM_OK;
 }
 
