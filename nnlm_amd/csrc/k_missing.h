@@ -1,0 +1,244 @@
+// k_missing.h -- square-loss half-step when A has missing entries.
+//
+// Reference: update_with_missing(), src/update_with_missing.cpp:58-139, methods 1 and 2.  Per column j the
+// reference restricts the contraction to non_missing = find_finite(A.col(j)) (:80-83) and forms a PER-COLUMN
+// Gram  WtW_j = Wt[:,nm] Wt[:,nm]^T  and cross product  Wt[:,nm] A[nm,j]  (:90-91), then applies the same
+// regularisation edits (:98-103) and the same per-column solvers.
+//
+// Here:
+//   * the cross product needs nothing new: the resident A holds 0 at missing positions, so the dense
+//     A-streaming kernels (k_xprod.h) already sum over finite rows only;
+//   * na_gram_kernel (one 256-thread block per column) forms G_j in fp64 as either the direct sum over finite
+//     rows or  G_full - sum over missing rows  (complement), whichever touches fewer rows;  the rows of the
+//     fixed factor are gathered from a row-major copy ([p][KP], 512 B per row);
+//   * colsolve_ls_kernel (one wavefront per column, lane = coordinate) runs SCD / Lee with that column's own G.
+//     Lane r keeps column r of G_j in VGPRs (G is symmetric), the sequential coordinate index q is wave
+//     uniform, so G[q][r] is an indirect VGPR read (s_set_gpr_idx) and x[q], mu[q] are v_readlane.
+//
+// The missing-entry index sets are 1-bit-per-entry masks built by the prep pass (exact, integer):
+//   miss  [mpad][npad/32]  bit (i%32) of word [j][i/32]   -- used by the H half-step (column j of A)
+//   missT [npad][mpad/32]  bit (j%32) of word [i][j/32]   -- used by the W half-step (row i of A)
+#pragma once
+#include "common.h"
+#include "k_sweep.h"
+
+// missT[i][j/32] bit j%32 = miss[j][i/32] bit i%32.  One thread per output word.
+__global__ __launch_bounds__(256) void miss_transpose_kernel(const uint32_t *__restrict__ miss, int npad, int mpad,
+                                                             uint32_t *__restrict__ missT)
+{
+    const int wj = blockIdx.x * 256 + threadIdx.x; // word index along j
+    const int i = blockIdx.y;
+    const int words_i = npad >> 5, words_j = mpad >> 5;
+    if (wj >= words_j) return;
+    uint32_t out = 0;
+    for (int b = 0; b < 32; b++) {
+        const int j = wj * 32 + b;
+        out |= ((miss[(size_t)j * words_i + (i >> 5)] >> (i & 31)) & 1u) << b;
+    }
+    missT[(size_t)i * words_j + wj] = out;
+}
+
+// Yrow[c][q] = Y[q][c] for q < KP (fp64), so that a row of the fixed factor is one contiguous 8*KP-byte read.
+__global__ __launch_bounds__(256) void factor_rows_kernel(const double *__restrict__ Y, int ld, int ncols, int KP,
+                                                          double *__restrict__ Yrow)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    for (int q = 0; q < KP; q++) Yrow[(size_t)c * KP + q] = Y[(size_t)q * ld + c];
+}
+
+// Per-column Gram.  bits: this column's missing mask over the contraction index (p bits, `words` words per
+// column); Yrow [p][KP]; Gfull [KP][KP]; Gcols [ncols][KP][KP].
+#define NAG_BATCH 32
+template <int NKQ>
+__global__ __launch_bounds__(256) void na_gram_kernel(const uint32_t *__restrict__ bits_all, int words, int p,
+                                                      const double *__restrict__ Yrow, const double *__restrict__ Gfull,
+                                                      double *__restrict__ Gcols)
+{
+    constexpr int KP = 16 * NKQ;
+    constexpr int NB = KP / 4; // 4x4 register blocks per side
+    __shared__ double rows[NAG_BATCH][KP];
+    __shared__ int sel[256];
+    __shared__ int nsel_s, cnt_s;
+    __shared__ int wcnt[4];
+    const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *bits = bits_all + (size_t)col * words;
+
+    // number of missing rows in this column
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    int c = 0;
+    for (int w = tid; w < (p + 31) / 32; w += 256) {
+        uint32_t v = bits[w];
+        if ((w + 1) * 32 > p) v &= (p & 31) ? ((1u << (p & 31)) - 1u) : 0xFFFFFFFFu;
+        c += __popc(v);
+    }
+    c = (int)wave_sum_ll(c);
+    if (lane == 0 && c) atomicAdd(&cnt_s, c);
+    __syncthreads();
+    const int nmiss = cnt_s;
+    const bool complement = nmiss * 2 <= p; // sum over the missing rows and subtract from the full Gram
+    const uint32_t want = complement ? 1u : 0u;
+
+    const int bq = tid / NB, br = tid % NB;
+    const bool owner = tid < NB * NB;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+
+    for (int base = 0; base < p; base += 256) {
+        // compact the selected row indices of this 256-candidate chunk (order preserved)
+        const int i = base + tid;
+        bool take = false;
+        if (i < p) take = ((bits[i >> 5] >> (i & 31)) & 1u) == want;
+        const unsigned long long bal = __ballot(take);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        if (take) sel[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        if (tid == 0) nsel_s = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+        const int nsel = nsel_s;
+        for (int b0 = 0; b0 < nsel; b0 += NAG_BATCH) {
+            const int nb = (nsel - b0 < NAG_BATCH) ? nsel - b0 : NAG_BATCH;
+            for (int e = tid; e < nb * KP; e += 256) rows[e / KP][e % KP] = Yrow[(size_t)sel[b0 + e / KP] * KP + (e % KP)];
+            __syncthreads();
+            if (owner)
+                for (int r = 0; r < nb; r++) {
+                    double a4[4], b4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        a4[t] = rows[r][4 * bq + t];
+                        b4[t] = rows[r][4 * br + t];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_fma(a4[a], b4[b], acc[a][b]);
+                }
+            __syncthreads();
+        }
+    }
+    if (owner) {
+        double *out = Gcols + (size_t)col * KP * KP;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int idx = (4 * bq + a) * KP + 4 * br + b;
+                out[idx] = complement ? Gfull[idx] - acc[a][b] : acc[a][b];
+            }
+    }
+}
+
+// One wavefront per column, lane = coordinate (k <= 64).  a.Graw is either one shared Gram (g_stride = 0) or the
+// per-column Grams (g_stride = KPg*KPg).  Same arithmetic as sweep_ls_kernel (k_sweep.h).
+template <int NKQ, int METHOD>
+__global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, size_t g_stride)
+{
+    constexpr int NCH = 2 * NKQ; // chunks of 8 coordinates
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= a.ncols) return; // whole wave
+    const int k = a.k;
+    const bool lv = lane < k;
+    const int lq = lv ? lane : 0;
+    const double *G = a.Graw + (size_t)col * g_stride;
+
+    unsigned long long mword = 0ull;
+    if (a.mask) mword = a.mask[col];
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const bool skip = a.mask && ((mword & kmask) == kmask); // arma::all(mask.col(j)), :75-76
+
+    // column `lane` of the edited G (= row `lane`, G is symmetric): g[q] = G[q][lane], as NCH vectors of 8 so that the
+    // wave-uniform index q can address it with s_set_gpr_idx
+    f64x8 g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int q = 8 * c + e;
+            double v = 0.0;
+            if (q < k && lv) {
+                v = G[(size_t)q * a.KPg + lane];
+                if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1; // :98-99
+                if (a.r1 != 0) v += a.r1;                          // :100-101
+                if (q == lane) v += NNLM_TINY;                     // :103
+            }
+            g[c][e] = v;
+        }
+    double gd = 1.0; // edited G[lane][lane]
+    if (lv) {
+        gd = G[(size_t)lq * a.KPg + lq];
+        if (a.r0 != a.r1) gd += a.r0 - a.r1;
+        if (a.r1 != 0) gd += a.r1;
+        gd += NNLM_TINY;
+    }
+    double x = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
+    double cv = 0.0;
+    if (lv)
+        for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)lq * a.ldc + col];
+    double v;
+    if (METHOD == 1) { // mu = G x - c (+ L1): lane r accumulates sum_q G[r][q] x[q] = sum_q g[q] * x_q
+        double s0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int qend = (k - 8 * c) < 8 ? (k - 8 * c) : 8;
+            for (int e = 0; e < qend; e++) s0 = __builtin_fma(g[c][e], __shfl(x, 8 * c + e, 64), s0);
+        }
+        v = s0 - cv;
+        if (a.r2 != 0) v += a.r2;
+        if (!lv) v = 0.0;
+    } else
+        v = cv;
+
+    int t = 0;
+    if (!skip) {
+        double rel = 1.0 + a.rel_tol;
+        for (; (unsigned)t < a.max_iter && rel > a.rel_tol; t++) {
+            rel = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int qend = (k - 8 * c) < 8 ? (k - 8 * c) : 8;
+                for (int e = 0; e < qend; e++) {
+                    const int q = 8 * c + e;
+                    if ((mword >> q) & 1ull) continue; // wave uniform
+                    const double xq = __shfl(x, q, 64);
+                    if (METHOD == 1) {
+                        const double muq = __shfl(v, q, 64), gqq = __shfl(gd, q, 64);
+                        double tmp = xq - muq / gqq;
+                        if (tmp < 0) tmp = 0;
+                        if (tmp != xq) { // uniform
+                            const double d = tmp - xq;
+                            v = __builtin_fma(d, g[c][e], v);
+                            const double er = 2 * fabs(xq - tmp) / (tmp + xq + NNLM_TINY);
+                            if (er > rel) rel = er;
+                            if (lane == q) x = tmp;
+                        }
+                    } else {
+                        const double dot = wave_sum(lv ? g[c][e] * x : 0.0);
+                        double tmp = dot + a.r2;
+                        tmp = __shfl(v, q, 64) / (tmp + NNLM_TINY);
+                        if (lane == q) x *= tmp;
+                        const double er = 2 * fabs(tmp - 1) / (tmp + 1);
+                        if (er > rel) rel = er;
+                    }
+                }
+            }
+        }
+    }
+    if (lv) {
+        a.X[(size_t)lane * a.ldx + col] = x;
+        if (a.op_mode == 1) {
+            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
+            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
+        } else if (a.op_mode == 2) {
+            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
+            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
+        }
+    }
+    if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
+}

@@ -13,6 +13,8 @@
 #include "common.h"
 #include "k_errors.h"
 #include "k_gram.h"
+#include "k_kl.h"
+#include "k_missing.h"
 #include "k_prep.h"
 #include "k_sweep.h"
 #include "k_xprod.h"
@@ -48,6 +50,7 @@ struct nnlm_handle {
     int n = 0, m = 0, npad = 0, mpad = 0;
     void *A = nullptr;          // T [mpad][npad]
     uint32_t *miss = nullptr;   // [mpad][npad/32]
+    uint32_t *missT = nullptr;  // [npad][mpad/32], only when any_missing
     bool any_missing = false;
     double n_non_missing = 0.0, kl_const = 0.0;
 
@@ -63,6 +66,8 @@ struct nnlm_handle {
     size_t Cx_elems = 0;
     double *gslabs = nullptr, *Graw = nullptr; // Graw = head of red
     double *red = nullptr;               // [KP*KP | KP*max(npad,mpad)]: the buffer one all-reduce sums
+    double *Yrow = nullptr;              // [max(npad,mpad)][KP] row-major copy of the fixed factor (NA path)
+    double *Gcols = nullptr;             // [max(n,m)][KP][KP] per-column Grams (NA path)
     double *partials = nullptr;
     size_t partials_elems = 0;
     double *scal = nullptr;              // 16 doubles of reduction results
@@ -224,7 +229,9 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Cx);
     hipFree(h->gslabs);
     hipFree(h->red);
-    h->red = nullptr;
+    hipFree(h->Yrow);
+    hipFree(h->Gcols);
+    h->red = h->Yrow = h->Gcols = nullptr;
     h->W64 = h->H64 = nullptr;
     h->Wop = h->Hop = nullptr;
     h->Wmask = h->Hmask = nullptr;
@@ -236,9 +243,11 @@ static void free_matrix(nnlm_handle *h)
 {
     hipFree(h->A);
     hipFree(h->miss);
+    hipFree(h->missT);
     hipFree(h->partials);
     h->A = nullptr;
     h->miss = nullptr;
+    h->missT = nullptr;
     h->partials = nullptr;
     h->n = h->m = 0;
 }
@@ -317,6 +326,13 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
     h->n_non_missing = cnt;
     h->any_missing = cnt != (double)n * (double)m;
     h->kl_const = klc / cnt; // mean((A+eps) log(A+eps) - A) over finite entries, src/nnmf.cpp:70,73
+    if (h->any_missing) { // row-wise view of the missing mask for the W half-step
+        const size_t wordsT = (size_t)h->npad * (h->mpad / 32);
+        HIPCHK(h, hipMalloc(&h->missT, wordsT * 4 + 64));
+        dim3 grid((h->mpad / 32 + 255) / 256, h->npad);
+        miss_transpose_kernel<<<grid, 256, 0, h->stream>>>(h->miss, h->npad, h->mpad, h->missT);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return NNLM_OK;
 }
 
@@ -551,14 +567,109 @@ static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
     }
 }
 
+template <typename T, int EPT>
+static void launch_kl_m(int method, const KlArgs &a, hipStream_t s)
+{
+    if (method == 3) kl_update_kernel<T, EPT, 3><<<a.ncols, KL_THREADS, 0, s>>>(a);
+    else kl_update_kernel<T, EPT, 4><<<a.ncols, KL_THREADS, 0, s>>>(a);
+}
+
+template <typename T>
+static void launch_kl(int method, const KlArgs &a, hipStream_t s)
+{
+    const int ept = (a.p + KL_THREADS - 1) / KL_THREADS;
+    if (ept <= 1) launch_kl_m<T, 1>(method, a, s);
+    else if (ept <= 2) launch_kl_m<T, 2>(method, a, s);
+    else if (ept <= 4) launch_kl_m<T, 4>(method, a, s);
+    else if (ept <= 8) launch_kl_m<T, 8>(method, a, s);
+    else if (ept <= 16) launch_kl_m<T, 16>(method, a, s);
+    else if (ept <= 24) launch_kl_m<T, 24>(method, a, s);
+    else if (ept <= 32) launch_kl_m<T, 32>(method, a, s);
+    else if (ept <= 40) launch_kl_m<T, 40>(method, a, s);
+    else if (ept <= 48) launch_kl_m<T, 48>(method, a, s);
+    else launch_kl_m<T, 64>(method, a, s);
+}
+
+template <int NKQ>
+static void launch_colsolve_m(int method, const SweepArgs &a, size_t g_stride, hipStream_t s)
+{
+    const int nb = (a.ncols + 3) / 4;
+    if (method == 1) colsolve_ls_kernel<NKQ, 1><<<nb, 256, 0, s>>>(a, g_stride);
+    else colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
+}
+
+static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
+{
+    switch (h->NKQ) {
+    case 1: launch_colsolve_m<1>(method, a, g_stride, h->stream); break;
+    case 2: launch_colsolve_m<2>(method, a, g_stride, h->stream); break;
+    case 3: launch_colsolve_m<3>(method, a, g_stride, h->stream); break;
+    default: launch_colsolve_m<4>(method, a, g_stride, h->stream); break;
+    }
+}
+
+static void launch_na_gram(nnlm_handle *h, const uint32_t *bits, int words, int p, int ncols)
+{
+    switch (h->NKQ) {
+    case 1: na_gram_kernel<1><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
+    case 2: na_gram_kernel<2><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
+    case 3: na_gram_kernel<3><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
+    default: na_gram_kernel<4><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
+    }
+}
+
+// KL methods: no Gram, no cross product -- one block per column streams the column of A and the fixed factor.
+static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method)
+{
+    if (h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods are not sharded across GPUs in this build");
+    KlArgs a;
+    a.k = h->k;
+    a.r0 = reg[0];
+    a.r1 = reg[1];
+    a.r2 = reg[2];
+    a.max_iter = inner_max_iter;
+    a.rel_tol = inner_rel_tol;
+    a.sweeps = h->sweeps;
+    a.A = h->A;
+    a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
+    if (which == 1) {
+        a.X = h->H64; a.ldx = h->mpad; a.Y = h->W64; a.ldy = h->npad;
+        a.a_col_stride = (size_t)h->npad; a.a_i_stride = 1;
+        a.bits = h->any_missing ? h->miss : nullptr; a.words = h->npad / 32;
+        a.p = h->n; a.ncols = h->m;
+        a.mask = h->has_hmask ? h->Hmask : nullptr;
+        a.op = h->Hop; a.op_mode = 2; a.op_ld = h->KP;
+    } else {
+        a.X = h->W64; a.ldx = h->npad; a.Y = h->H64; a.ldy = h->mpad;
+        a.a_col_stride = 1; a.a_i_stride = (size_t)h->npad;
+        a.bits = h->any_missing ? h->missT : nullptr; a.words = h->mpad / 32;
+        a.p = h->m; a.ncols = h->n;
+        a.mask = h->has_wmask ? h->Wmask : nullptr;
+        a.op = h->Wop; a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1; a.op_ld = h->npad;
+    }
+    if (a.p > KL_MAX_P) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods support a contraction length up to %d (got %d)", KL_MAX_P, a.p);
+    {
+        ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
+        if (h->prec == NNLM_PREC_F64) launch_kl<double>(method, a, h->stream);
+        else launch_kl<float>(method, a, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    return NNLM_OK;
+}
+
 static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
                      bool partial_only = false)
 {
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
-    if (method >= 3) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods (3, 4) are not implemented in this build yet");
-    if (h->any_missing) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not implemented in this build yet");
     HIPCHK(h, hipSetDevice(h->device));
+    if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method);
+    if (h->any_missing && h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
+    if (h->any_missing && !h->Gcols) { // NA path workspaces, on first use
+        const int big = h->npad > h->mpad ? h->npad : h->mpad;
+        HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
+        HIPCHK(h, hipMalloc(&h->Gcols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * h->KP * 8));
+    }
     const HalfPlan p = plan_half(h, which, h->rank, h->nranks);
     // 1. cross product slabs
     {
@@ -627,7 +738,17 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             a.op_ld = h->npad;
         }
         a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
-        launch_sweep(h, method, a);
+        if (h->any_missing) {
+            // per-column Gram over the finite rows of each column (src/update_with_missing.cpp:90), then the solver
+            const int p_len = (which == 1) ? h->n : h->m;
+            const double *Ymaster = (which == 1) ? h->W64 : h->H64;
+            const int ldy = (which == 1) ? h->npad : h->mpad;
+            factor_rows_kernel<<<(p_len + 255) / 256, 256, 0, h->stream>>>(Ymaster, ldy, p_len, h->KP, h->Yrow);
+            launch_na_gram(h, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, a.ncols);
+            a.Graw = h->Gcols;
+            launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
+        } else
+            launch_sweep(h, method, a);
     }
     HIPCHK(h, hipGetLastError());
     return NNLM_OK;
