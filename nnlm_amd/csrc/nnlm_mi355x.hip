@@ -545,26 +545,56 @@ static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, in
     *nslabs = nb;
 }
 
-template <int NCH>
+template <int R, int L>
 static void launch_sweep_m(int method, const SweepArgs &a, hipStream_t s)
 {
-    const int nb = (a.ncols + 63) / 64;
-    if (method == 1) sweep_ls_kernel<NCH, 1><<<nb, 64, 0, s>>>(a);
-    else sweep_ls_kernel<NCH, 2><<<nb, 64, 0, s>>>(a);
+    const int cpw = 64 / L; // columns per wavefront
+    const int nb = (a.ncols + cpw - 1) / cpw;
+    if (method == 1) sweep_ls_kernel<R, L, 1><<<nb, 64, 0, s>>>(a);
+    else sweep_ls_kernel<R, L, 2><<<nb, 64, 0, s>>>(a);
+}
+
+// registers per lane R = STEP * idx, idx = 1..8
+template <int STEP, int L>
+static void launch_sweep_l(int idx, int method, const SweepArgs &a, hipStream_t s)
+{
+    switch (idx) {
+    case 1: launch_sweep_m<1 * STEP, L>(method, a, s); break;
+    case 2: launch_sweep_m<2 * STEP, L>(method, a, s); break;
+    case 3: launch_sweep_m<3 * STEP, L>(method, a, s); break;
+    case 4: launch_sweep_m<4 * STEP, L>(method, a, s); break;
+    case 5: launch_sweep_m<5 * STEP, L>(method, a, s); break;
+    case 6: launch_sweep_m<6 * STEP, L>(method, a, s); break;
+    case 7: launch_sweep_m<7 * STEP, L>(method, a, s); break;
+    default: launch_sweep_m<8 * STEP, L>(method, a, s); break;
+    }
+}
+
+// Lanes per column.  The sweep is bound by the per-wavefront issue rate (fp64 VALU: one instruction per 8 cycles per
+// wave, measured), so fewer FMAs per lane (larger L) wins as long as the SIMDs are not oversubscribed: L = 4 up to
+// 4 wavefronts per SIMD (measured at config 2: L=4 0.56 ms, L=2 0.85 ms, L=1 1.5 ms per half-step).
+// NNLM_SWEEP_L overrides it for experiments.
+static int sweep_lanes_per_column(int ncols)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("NNLM_SWEEP_L");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    const long slots = 1024L * 4; // SIMDs x wavefronts per SIMD
+    if (((long)ncols * 4 + 63) / 64 <= slots) return 4;
+    if (((long)ncols * 2 + 63) / 64 <= slots) return 2;
+    return 1;
 }
 
 static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
-    switch (h->KP8 / 8) {
-    case 1: launch_sweep_m<1>(method, a, h->stream); break;
-    case 2: launch_sweep_m<2>(method, a, h->stream); break;
-    case 3: launch_sweep_m<3>(method, a, h->stream); break;
-    case 4: launch_sweep_m<4>(method, a, h->stream); break;
-    case 5: launch_sweep_m<5>(method, a, h->stream); break;
-    case 6: launch_sweep_m<6>(method, a, h->stream); break;
-    case 7: launch_sweep_m<7>(method, a, h->stream); break;
-    default: launch_sweep_m<8>(method, a, h->stream); break;
-    }
+    const int L = sweep_lanes_per_column(a.ncols);
+    const int rneed = (h->k + L - 1) / L;
+    if (L == 4) launch_sweep_l<2, 4>((rneed + 1) / 2, method, a, h->stream);      // R = 2..16, k <= 64
+    else if (L == 2) launch_sweep_l<4, 2>((rneed + 3) / 4, method, a, h->stream); // R = 4..32
+    else launch_sweep_l<8, 1>((rneed + 7) / 8, method, a, h->stream);             // R = 8..64
 }
 
 template <typename T, int EPT>
