@@ -82,6 +82,136 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// F32 fast path of the error block.  128 x 128 tile of W H per 256-thread block:
+//   * the k x 128 slices of the fp32 [kq][col] copies of W and H go to LDS with global_load_lds ([kq][128]);
+//   * each wavefront forms a 64 x 64 block as 2 x 2 v_mfma_f32_32x32x2_f32 tiles with M = j and N = i, so that in the
+//     accumulator layout (column = lane & 31) the 32 lanes of a half-wave hold 32 CONSECUTIVE rows i of one column j:
+//     the matching A entries are read as full 128-byte lines (the generic kernel above reads 64-byte pieces);
+//   * per tile the two sums are accumulated in fp32 over the lane's 16 entries, then folded into fp64.
+// partial: [gridDim.y*gridDim.x][2] as above.
+// ------------------------------------------------------------------------------------------------
+#define ERRF_TILE 128
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict__ A, int lda, const uint32_t *__restrict__ miss,
+                                                         const float *__restrict__ Wf, int ldw,
+                                                         const float *__restrict__ Hf, int ldh, int n, int m, int k2,
+                                                         double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_err[];
+    float *Ws = (float *)smem_err;               // [k2][128]
+    float *Hs = Ws + (size_t)k2 * ERRF_TILE;      // [k2][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * ERRF_TILE, j0 = blockIdx.y * ERRF_TILE;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ib = 64 * (wave & 1), jb = 64 * (wave >> 1);
+
+    // 1. issue the HBM reads of this wavefront's 64 x 64 block of A first: their latency hides under the operand
+    //    staging and the MFMA phase.  D layout 32x32: row M = (r&3) + 8*(r>>2) + 4*(lane>>5), column N = lane & 31.
+    float av[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int i = i0 + ib + 32 * b + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                av[a][b][r] = A[(size_t)j * lda + i];
+            }
+        }
+
+    // 2. k x 128 slices of W and H (fp32 [kq][col] copies) straight into LDS with global_load_lds: one instruction
+    //    moves two 512-byte rows; all of them are in flight at once and use no VGPRs
+    {
+        const int nrow2 = k2 / 2; // instructions per matrix
+        for (int t = wave; t < 2 * nrow2; t += 4) {
+            const bool isw = t < nrow2;
+            const int tt = isw ? t : t - nrow2;
+            const int row = 2 * tt + (lane >> 5);
+            const float *src = isw ? (Wf + (size_t)row * ldw + i0 + 4 * (lane & 31)) : (Hf + (size_t)row * ldh + j0 + 4 * (lane & 31));
+            glds16(src, (unsigned char *)(isw ? Ws : Hs) + (size_t)tt * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // 3. W H for the block: 2 x 2 tiles of 32 x 32, contraction k
+    f32x16 acc[2][2]; // [tj][ti]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    for (int q = lh; q < k2; q += 2) {
+        float hj[2], wi[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            hj[t] = Hs[(size_t)q * ERRF_TILE + jb + 32 * t + l31];
+            wi[t] = Ws[(size_t)q * ERRF_TILE + ib + 32 * t + l31];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(hj[a], wi[b], acc[a][b], 0, 0, 0);
+    }
+
+    // 4. the two sums
+    const bool interior = (i0 + ERRF_TILE <= n) && (j0 + ERRF_TILE <= m) && (miss == nullptr);
+    const int words = lda >> 5;
+    double s2 = 0.0, skl = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int i = i0 + ib + 32 * b + l31;
+            float p2 = 0.f, pk = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float ah = acc[a][b][r], aa = av[a][b][r];
+                const float d = aa - ah;
+                const float lg = __logf(ah + (float)NNLM_TINY);
+                float t2 = d * d;
+                float tk = __builtin_fmaf(-(aa + (float)NNLM_TINY), lg, ah);
+                if (!interior) {
+                    bool valid = (i < n) && (j < m);
+                    if (miss && valid) valid = !((miss[(size_t)j * words + (i >> 5)] >> (i & 31)) & 1u);
+                    if (!valid) {
+                        t2 = 0.f;
+                        tk = 0.f;
+                    }
+                }
+                p2 += t2;
+                pk += tk;
+            }
+            s2 += (double)p2;
+            skl += (double)pk;
+        }
+    __shared__ double red[2][4];
+    s2 = wave_sum(s2);
+    skl = wave_sum(skl);
+    if (lane == 0) {
+        red[0][wave] = s2;
+        red[1][wave] = skl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial[2 * blk] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        partial[2 * blk + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
+
+// Xf[q][c] = (float) X[q][c]: fp32 [kq][col] copy of a factor for errors_f32_kernel.
+__global__ __launch_bounds__(256) void factor_to_f32_kernel(const double *__restrict__ X, size_t count, float *__restrict__ Xf)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < count) Xf[e] = (float)X[e];
+}
+
 // Penalty sums for one factor X [KP][ld] (src/nnmf.cpp:224-240):
 //   partial[blk] = {sum x^2, sum_col (sum_q x[q,col])^2, sum x} over the block's 256 columns.
 __global__ __launch_bounds__(256) void penalty_kernel(const double *__restrict__ X, int ld, int ncols, int k,

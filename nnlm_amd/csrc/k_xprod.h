@@ -12,7 +12,9 @@
 // RCCL all-reduce) sums the slabs in a fixed order -> deterministic.
 //
 // MFMA: 16x16x4 (f32 or f64 inputs), one operand element per lane.  Tiles of A and of the factor
-// go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered; operand
+// go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a ring of XPROD_NBUF stage
+// buffers: two stages (64 KiB of A per CU) stay in flight while one is consumed, ordered by counted
+// `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the queue); operand
 // fragments come out of LDS as 16-byte ds_read_b128.  In f32 mode partial sums are kept in f32
 // for at most XPROD_FLUSH_ELEMS contraction elements and then folded into fp64 accumulators
 // (SURVEY.md section 7 "precision ladder").
@@ -28,10 +30,28 @@
 #define XPROD_NT_ROWS 32          // contraction rows j per stage (NT)
 #define XPROD_A_IMG_BYTES 32768   // A image per stage, both kernels
 
-__host__ __device__ static inline int xprod_tn_lds_bytes(int KP) { return 2 * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB); }
+#define XPROD_NBUF 3              // LDS stage buffers: one being consumed, two in flight from HBM
+
+__host__ __device__ static inline int xprod_tn_lds_bytes(int KP) { return XPROD_NBUF * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB); }
 template <typename T> __host__ __device__ static inline int xprod_nt_lds_bytes(int KP)
 {
-    return 2 * (XPROD_A_IMG_BYTES + XPROD_NT_ROWS * KP * (int)sizeof(T));
+    return XPROD_NBUF * (XPROD_A_IMG_BYTES + XPROD_NT_ROWS * KP * (int)sizeof(T));
+}
+
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: waits until at most n of this wavefront's vector-memory
+// operations are outstanding.  global_load_lds completes in issue order, so "n = loads of the newest stage" means
+// "every older stage has landed".
+__device__ static inline void wait_vmcnt(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -92,13 +112,18 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         }
     };
 
+    // loads one wavefront issues per stage (A image: 32 KiB / 1 KiB / 4 waves; factor image: KP/4 instructions / 4 waves)
+    const int per_stage = XPROD_A_IMG_BYTES / 1024 / 4 + NKQ;
     if (st0 < st1) issue(st0, smem);
+    if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
-        unsigned char *buf = smem + ((st - st0) & 1) * BUF;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * BUF);
+        unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
+        // stage `st` has landed once at most the newer stage's loads are outstanding; the barrier then also tells
+        // every wave that stage st-1 has been consumed, so its buffer may be refilled with stage st+2
+        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int phys = ((lg + 4 * kk) ^ l15) * 16;
@@ -209,13 +234,17 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             glds16(ysrc + u * 1024 + lane * 16, buf + XPROD_A_IMG_BYTES + u * 1024);
     };
 
+    // loads THIS wavefront issues per stage: 8 rows of A + its share of the YIMG/1024 factor-image instructions
+    const int ycnt = YIMG / 1024;
+    const int per_stage = XPROD_NT_ROWS / 4 + ((wave < ycnt) ? (ycnt - wave + 3) / 4 : 0);
     if (st0 < st1) issue(st0, smem);
+    if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
-        unsigned char *buf = smem + ((st - st0) & 1) * BUF;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * BUF);
+        unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
+        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
 #pragma unroll
         for (int kk = 0; kk < XPROD_NT_ROWS / 4; kk++) {
             const int row = lg + 4 * kk;
@@ -260,19 +289,27 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             }
         }
     }
-    // epilogue: tile (e, t): M index -> i = i0 + wave*16*EPV + EPV*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t
+    // epilogue: tile (e, t): M index -> i = i0 + wave*16*EPV + EPV*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t.
+    // For a fixed (t, r) the EPV tiles e = 0..EPV-1 of a lane are EPV consecutive i: one 16/32-byte store.
     double *out = Cx + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
-    for (int e = 0; e < EPV; e++)
+    for (int t = 0; t < NKQ; t++)
 #pragma unroll
-        for (int t = 0; t < NKQ; t++)
+        for (int r = 0; r < 4; r++) {
+            const int kq = NKQ * l15 + t;
+            const int i = i0 + wave * 16 * EPV + EPV * M::row_of(lane, r);
+            double vv[EPV];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int kq = NKQ * l15 + t;
-                const int i = i0 + wave * 16 * EPV + EPV * M::row_of(lane, r) + e;
-                double v;
-                if constexpr (sizeof(T) == 4) v = acc64[e][t][r] + (double)acc[e][t][r];
-                else v = acc[e][t][r];
-                out[(size_t)kq * ldc + i] = v;
+            for (int e = 0; e < EPV; e++) {
+                if constexpr (sizeof(T) == 4) vv[e] = acc64[e][t][r] + (double)acc[e][t][r];
+                else vv[e] = acc[e][t][r];
             }
+            double *dst = out + (size_t)kq * ldc + i;
+            if constexpr (EPV == 4) {
+                *(f64x2 *)dst = f64x2{vv[0], vv[1]};
+                *(f64x2 *)(dst + 2) = f64x2{vv[2], vv[3]};
+            } else {
+                *(f64x2 *)dst = f64x2{vv[0], vv[1]};
+            }
+        }
 }

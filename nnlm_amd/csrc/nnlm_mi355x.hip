@@ -58,6 +58,7 @@ struct nnlm_handle {
     int k = 0, NKQ = 0, KP = 0, KP8 = 0;
     double *W64 = nullptr, *H64 = nullptr;        // [KP][npad], [KP][mpad]
     void *Wop = nullptr, *Hop = nullptr;          // T [KP][npad] (aliases W64 in f64 mode), T [mpad][KP]
+    float *Hkq = nullptr;                         // fp32 [KP][mpad] copy of H, refreshed by nnlm_errors (f32 mode)
     unsigned long long *Wmask = nullptr, *Hmask = nullptr; // per column bitmask, or null
     bool has_wmask = false, has_hmask = false;
 
@@ -224,6 +225,8 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->W64);
     hipFree(h->H64);
     hipFree(h->Hop);
+    hipFree(h->Hkq);
+    h->Hkq = nullptr;
     hipFree(h->Wmask);
     hipFree(h->Hmask);
     hipFree(h->Cx);
@@ -348,13 +351,25 @@ extern "C" int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_
 // ---------------------------------------------------------------------------------------------
 // factors
 // ---------------------------------------------------------------------------------------------
+// Split-K factor S for tiles_x output tiles: the xprod kernels run one 4-wave block per CU (their LDS ring fills the
+// CU), so the launch executes in ceil(blocks/256) rounds; pick the S (<= 16, each split at least 8 stages deep) whose
+// last round is fullest, preferring fewer slabs on ties.
 static int split_plan(int tiles_x, int stages, int *S, int *sps)
 {
-    int s = (512 + tiles_x - 1) / tiles_x;
-    if (s < 1) s = 1;
-    if (s > stages) s = stages;
-    if (s < 1) s = 1;
-    int per = (stages + s - 1) / s;
+    const int cus = 256;
+    int best_s = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= 16; s++) {
+        if (s > 1 && stages / s < 8) break;
+        const long blocks = (long)tiles_x * s;
+        const long rounds = (blocks + cus - 1) / cus;
+        const double eff = (double)blocks / (double)(rounds * cus);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_s = s;
+        }
+    }
+    int per = (stages + best_s - 1) / best_s;
     if (per < 1) per = 1;
     *S = (stages + per - 1) / per;
     if (*S < 1) *S = 1;
@@ -427,6 +442,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         if (h->prec == NNLM_PREC_F64) h->Wop = h->W64;
         else HIPCHK(h, hipMalloc(&h->Wop, (size_t)h->KP * h->npad * es));
         HIPCHK(h, hipMalloc(&h->Hop, (size_t)h->mpad * h->KP * es + 4096));
+        if (h->prec == NNLM_PREC_F32) HIPCHK(h, hipMalloc(&h->Hkq, (size_t)h->KP * h->mpad * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * 8));
         HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * 8));
         // split-K slabs: sized for the worst case over ranks (nranks = 1 gives the largest S)
@@ -862,15 +878,23 @@ extern "C" int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double 
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_errors: matrix and factors must be set first");
     HIPCHK(h, hipSetDevice(h->device));
     const int k4 = round_up_i(h->k, 4);
-    dim3 grid(h->npad / ERR_TILE, h->mpad / ERR_TILE);
-    const size_t nb = (size_t)grid.x * grid.y;
     {
         ProfScope ps(h, P_ERRORS);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
-        if (h->prec == NNLM_PREC_F64)
+        size_t nb;
+        if (h->prec == NNLM_PREC_F64) {
+            dim3 grid(h->npad / ERR_TILE, h->mpad / ERR_TILE);
+            nb = (size_t)grid.x * grid.y;
             errors_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
-        else
-            errors_kernel<float><<<grid, 256, 0, h->stream>>>((const float *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
+        } else {
+            dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
+            nb = (size_t)grid.x * grid.y;
+            const int k2 = round_up_i(h->k, 2);
+            const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
+            const size_t cnt = (size_t)h->KP * h->mpad;
+            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
+            errors_f32_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials);
+        }
         reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, nb, 2, h->scal);
     }
     const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
