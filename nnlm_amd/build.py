@@ -20,8 +20,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-shared", "-fPIC",
-           "-o", OUT, SRC]
+    # -amdgpu-mfma-vgpr-form: keep MFMA C/D operands in VGPRs (gfx950 has a unified register file); the sweep kernel
+    # reads and rewrites single accumulator entries between MFMAs and would otherwise shuttle whole tiles VGPR<->AGPR
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-shared", "-fPIC", "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

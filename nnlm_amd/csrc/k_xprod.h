@@ -14,22 +14,24 @@
 // MFMA: 16x16x4 (f32 or f64 inputs), one operand element per lane.  Tiles of A and of the factor
 // go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a ring of XPROD_NBUF stage
 // buffers: two stages (64 KiB of A per CU) stay in flight while one is consumed, ordered by counted
-// `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the queue); operand
-// fragments come out of LDS as 16-byte ds_read_b128.  In f32 mode partial sums are kept in f32
-// for at most XPROD_FLUSH_ELEMS contraction elements and then folded into fp64 accumulators
-// (SURVEY.md section 7 "precision ladder").
+// `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the queue).  A block is 8
+// wavefronts = 2 per SIMD, each owning one 16-row M-tile of the stage: while one wave of a SIMD issues
+// its LDS fragment reads / DMA, the other keeps the matrix pipe busy.  Fragments leave LDS as
+// ds_read_b128 (TN) / ds_read_b64 (NT A side).  In f32 mode partial sums are kept in f32 for at most
+// XPROD_FLUSH_ELEMS contraction elements and then folded into fp64 accumulators (SURVEY.md section 7
+// "precision ladder").
 //
 // All operands are zero padded to full tiles, so there are no bounds checks in the hot loop.
 #pragma once
 #include "common.h"
 
-#define XPROD_THREADS 256
+#define XPROD_THREADS 512
+#define XPROD_WAVES 8
 #define XPROD_FLUSH_ELEMS 256
 #define XPROD_ROWB 256            // bytes per LDS row of the TN images (one 16-lane group per row)
-#define XPROD_TN_BJ 128           // columns j per block (TN)
+#define XPROD_TN_BJ 128           // columns j per block (TN) = 8 waves x 16
 #define XPROD_NT_ROWS 32          // contraction rows j per stage (NT)
 #define XPROD_A_IMG_BYTES 32768   // A image per stage, both kernels
-
 #define XPROD_NBUF 3              // LDS stage buffers: one being consumed, two in flight from HBM
 
 __host__ __device__ static inline int xprod_tn_lds_bytes(int KP) { return XPROD_NBUF * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB); }
@@ -45,14 +47,17 @@ __device__ static inline void wait_vmcnt(int n)
 {
     switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
+
+// number of indices u in {wave, wave + 8, ...} below cnt
+__device__ static inline int strided_count(int wave, int cnt) { return (wave < cnt) ? (cnt - wave + XPROD_WAVES - 1) / XPROD_WAVES : 0; }
 
 // ------------------------------------------------------------------------------------------------
 // TN: contraction along i (contiguous in memory).
@@ -63,6 +68,7 @@ __device__ static inline void wait_vmcnt(int n)
 // (physical slot = logical slot ^ (r & 15)) so that the fragment reads (16 lanes = 16 different
 // rows, same logical slot) are bank-conflict free.  global_load_lds writes LDS linearly, so the
 // swizzle is applied to the per-lane GLOBAL source address (cdna_hip_programming.md rule 21).
+// Wave w owns image rows (columns j) [16w, 16w+16): one M-tile x NKQ N-tiles.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKQ>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__restrict__ A, int lda,
@@ -86,34 +92,32 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
 
-    acc_t acc[2][NKQ];
-    f64x4 acc64[2][NKQ];
+    acc_t acc[NKQ];
+    f64x4 acc64[NKQ];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NKQ; b++) {
-            acc[a][b] = acc_t{0, 0, 0, 0};
-            acc64[a][b] = f64x4{0, 0, 0, 0};
-        }
+    for (int b = 0; b < NKQ; b++) {
+        acc[b] = acc_t{0, 0, 0, 0};
+        acc64[b] = f64x4{0, 0, 0, 0};
+    }
 
     auto issue = [&](int st, unsigned char *buf) {
         const size_t i0 = (size_t)st * CE;
 #pragma unroll
-        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += 4) {
+        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
             const int row = 4 * t + lg;
             const int s = l15 ^ (row & 15);
             glds16(A + (size_t)(j0 + row) * lda + i0 + s * EPV, buf + t * 1024);
         }
 #pragma unroll
-        for (int t = wave; t < KP / 4; t += 4) {
+        for (int t = wave; t < KP / 4; t += XPROD_WAVES) {
             const int row = 4 * t + lg;
             const int s = l15 ^ (row & 15);
             glds16(Yop + (size_t)row * ldy + i0 + s * EPV, buf + XPROD_A_IMG_BYTES + t * 1024);
         }
     };
 
-    // loads one wavefront issues per stage (A image: 32 KiB / 1 KiB / 4 waves; factor image: KP/4 instructions / 4 waves)
-    const int per_stage = XPROD_A_IMG_BYTES / 1024 / 4 + NKQ;
+    // loads THIS wavefront issues per stage (A image: 32 instructions over 8 waves; factor image: KP/4 instructions)
+    const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, KP / 4);
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     int since_flush = 0;
@@ -127,12 +131,11 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int phys = ((lg + 4 * kk) ^ l15) * 16;
-            T a[2][EPV], b[NKQ][EPV];
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-                const int row = 32 * wave + 16 * mt + l15;
+            T a[EPV], b[NKQ][EPV];
+            {
+                const int row = 16 * wave + l15;
                 const f32x4 raw = *(const f32x4 *)(buf + row * XPROD_ROWB + phys);
-                __builtin_memcpy(a[mt], &raw, 16);
+                __builtin_memcpy(a, &raw, 16);
             }
 #pragma unroll
             for (int nt = 0; nt < NKQ; nt++) {
@@ -143,39 +146,33 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
 #pragma unroll
             for (int e = 0; e < EPV; e++)
 #pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int nt = 0; nt < NKQ; nt++) acc[mt][nt] = M::mma(a[mt][e], b[nt][e], acc[mt][nt]);
+                for (int nt = 0; nt < NKQ; nt++) acc[nt] = M::mma(a[e], b[nt][e], acc[nt]);
         }
         if constexpr (sizeof(T) == 4) {
             if (++since_flush == FL) {
                 since_flush = 0;
 #pragma unroll
-                for (int a = 0; a < 2; a++)
+                for (int b = 0; b < NKQ; b++) {
 #pragma unroll
-                    for (int b = 0; b < NKQ; b++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc64[a][b][r] += (double)acc[a][b][r];
-                        acc[a][b] = acc_t{0, 0, 0, 0};
-                    }
+                    for (int r = 0; r < 4; r++) acc64[b][r] += (double)acc[b][r];
+                    acc[b] = acc_t{0, 0, 0, 0};
+                }
             }
         }
     }
     // epilogue: D[M = j-row, N = kq]
     double *out = Cx + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int nt = 0; nt < NKQ; nt++)
 #pragma unroll
-        for (int nt = 0; nt < NKQ; nt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int kq = 16 * nt + l15;
-                const int j = j0 + 32 * wave + 16 * mt + M::row_of(lane, r);
-                double v;
-                if constexpr (sizeof(T) == 4) v = acc64[mt][nt][r] + (double)acc[mt][nt][r];
-                else v = acc[mt][nt][r];
-                out[(size_t)kq * ldc + j] = v;
-            }
+        for (int r = 0; r < 4; r++) {
+            const int kq = 16 * nt + l15;
+            const int j = j0 + 16 * wave + M::row_of(lane, r);
+            double v;
+            if constexpr (sizeof(T) == 4) v = acc64[nt][r] + (double)acc[nt][r];
+            else v = acc[nt][r];
+            out[(size_t)kq * ldc + j] = v;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,11 +180,11 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
 //   A      [mpad][lda], Yop [mpad][KP] (row j, kq fastest), Cx [S][KP][ldc] fp64, ldc >= npad
 //   grid   (npad/BI, S) with BI = 64*EPV output rows i per block (256 f32 / 128 f64)
 //   stage  = 32 contraction rows j; an image row is 1 KiB of one column of A = one
-//            global_load_lds instruction.  Fragment reads walk 16-byte slots inside a row
-//            (16 lanes) and 4 consecutive rows (lane groups): conflict free without a swizzle.
-// Lane (l&15) of an A fragment holds EPV consecutive i (one per M-tile e); lane (l&15) of a factor
-// fragment holds NKQ consecutive kq (one per N-tile t): the MFMA row/column <-> (i, kq) map is a
-// permutation that is undone in the epilogue.
+//            global_load_lds instruction.  Fragment reads walk 8-byte slots inside a row
+//            (16 lanes) and 4 consecutive rows (lane groups).
+// Wave w owns rows i [w*BI/8, (w+1)*BI/8).  Lane (l&15) of an A fragment holds MT = EPV/2 consecutive i
+// (one per M-tile e); lane (l&15) of a factor fragment holds NKQ consecutive kq (one per N-tile t):
+// the MFMA row/column <-> (i, kq) map is a permutation that is undone in the epilogue.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKQ>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__restrict__ A, int lda,
@@ -198,6 +195,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     constexpr int EPV = M::EPV;
+    constexpr int MT = EPV / 2;                       // M-tiles per wave (8-byte A fragment)
     constexpr int KP = 16 * NKQ;
     constexpr int BI = 64 * EPV;
     constexpr int YROW = KP * (int)sizeof(T);          // bytes of one factor row
@@ -213,10 +211,10 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
 
-    acc_t acc[EPV][NKQ];
-    f64x4 acc64[EPV][NKQ];
+    acc_t acc[MT][NKQ];
+    f64x4 acc64[MT][NKQ];
 #pragma unroll
-    for (int a = 0; a < EPV; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < NKQ; b++) {
             acc[a][b] = acc_t{0, 0, 0, 0};
@@ -226,17 +224,16 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
     auto issue = [&](int st, unsigned char *buf) {
         const size_t jb = (size_t)st * XPROD_NT_ROWS;
 #pragma unroll
-        for (int t = wave; t < XPROD_NT_ROWS; t += 4)
+        for (int t = wave; t < XPROD_NT_ROWS; t += XPROD_WAVES)
             glds16(A + (jb + t) * lda + i0 + lane * EPV, buf + t * 1024);
         const unsigned char *ysrc = (const unsigned char *)(Yop + jb * KP);
 #pragma unroll
-        for (int u = wave; u < YIMG / 1024; u += 4)
+        for (int u = wave; u < YIMG / 1024; u += XPROD_WAVES)
             glds16(ysrc + u * 1024 + lane * 16, buf + XPROD_A_IMG_BYTES + u * 1024);
     };
 
-    // loads THIS wavefront issues per stage: 8 rows of A + its share of the YIMG/1024 factor-image instructions
-    const int ycnt = YIMG / 1024;
-    const int per_stage = XPROD_NT_ROWS / 4 + ((wave < ycnt) ? (ycnt - wave + 3) / 4 : 0);
+    // loads THIS wavefront issues per stage: 4 rows of A + its share of the YIMG/1024 factor-image instructions
+    const int per_stage = XPROD_NT_ROWS / XPROD_WAVES + strided_count(wave, YIMG / 1024);
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     int since_flush = 0;
@@ -248,10 +245,10 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
 #pragma unroll
         for (int kk = 0; kk < XPROD_NT_ROWS / 4; kk++) {
             const int row = lg + 4 * kk;
-            T a[EPV], b[NKQ];
+            T a[MT], b[NKQ];
             {
-                const f32x4 raw = *(const f32x4 *)(buf + row * 1024 + wave * 256 + l15 * 16);
-                __builtin_memcpy(a, &raw, 16);
+                const double raw = *(const double *)(buf + row * 1024 + wave * 128 + l15 * 8);
+                __builtin_memcpy(a, &raw, 8);
             }
             {
                 const unsigned char *p = buf + XPROD_A_IMG_BYTES + row * YROW + l15 * (NKQ * (int)sizeof(T));
@@ -271,7 +268,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
                 }
             }
 #pragma unroll
-            for (int e = 0; e < EPV; e++)
+            for (int e = 0; e < MT; e++)
 #pragma unroll
                 for (int t = 0; t < NKQ; t++) acc[e][t] = M::mma(a[e], b[t], acc[e][t]);
         }
@@ -279,7 +276,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             if (++since_flush == FL) {
                 since_flush = 0;
 #pragma unroll
-                for (int a = 0; a < EPV; a++)
+                for (int a = 0; a < MT; a++)
 #pragma unroll
                     for (int b = 0; b < NKQ; b++) {
 #pragma unroll
@@ -289,27 +286,23 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             }
         }
     }
-    // epilogue: tile (e, t): M index -> i = i0 + wave*16*EPV + EPV*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t.
-    // For a fixed (t, r) the EPV tiles e = 0..EPV-1 of a lane are EPV consecutive i: one 16/32-byte store.
+    // epilogue: tile (e, t): M index -> i = i0 + wave*16*MT + MT*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t.
+    // For a fixed (t, r) the MT tiles of a lane are MT consecutive i.
     double *out = Cx + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
     for (int t = 0; t < NKQ; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int kq = NKQ * l15 + t;
-            const int i = i0 + wave * 16 * EPV + EPV * M::row_of(lane, r);
-            double vv[EPV];
+            const int i = i0 + wave * 16 * MT + MT * M::row_of(lane, r);
+            double vv[MT];
 #pragma unroll
-            for (int e = 0; e < EPV; e++) {
+            for (int e = 0; e < MT; e++) {
                 if constexpr (sizeof(T) == 4) vv[e] = acc64[e][t][r] + (double)acc[e][t][r];
                 else vv[e] = acc[e][t][r];
             }
             double *dst = out + (size_t)kq * ldc + i;
-            if constexpr (EPV == 4) {
-                *(f64x2 *)dst = f64x2{vv[0], vv[1]};
-                *(f64x2 *)(dst + 2) = f64x2{vv[2], vv[3]};
-            } else {
-                *(f64x2 *)dst = f64x2{vv[0], vv[1]};
-            }
+            if constexpr (MT == 2) *(f64x2 *)dst = f64x2{vv[0], vv[1]};
+            else dst[0] = vv[0];
         }
 }

@@ -17,6 +17,7 @@
 #include "k_missing.h"
 #include "k_prep.h"
 #include "k_sweep.h"
+#include "k_sweep_mfma.h"
 #include "k_xprod.h"
 
 #include <dlfcn.h>
@@ -604,8 +605,34 @@ static int sweep_lanes_per_column(int ncols)
     return 1;
 }
 
+// SCD-LS on the matrix cores (k_sweep_mfma.h); NNLM_SWEEP_MFMA=0 falls back to the VALU kernel for A/B runs.
+static bool use_mfma_sweep()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNLM_SWEEP_MFMA");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
+    if (method == 1 && use_mfma_sweep()) {
+        const int nb = (a.ncols + 63) / 64;
+        const bool hm = a.mask != nullptr;
+#define NNLM_MFMA_SWEEP(NT_)                                                               \
+    if (hm) sweep_scd_mfma_kernel<NT_, true><<<nb, 256, 0, h->stream>>>(a);                \
+    else sweep_scd_mfma_kernel<NT_, false><<<nb, 256, 0, h->stream>>>(a);
+        switch (h->NKQ) {
+        case 1: NNLM_MFMA_SWEEP(1) break;
+        case 2: NNLM_MFMA_SWEEP(2) break;
+        case 3: NNLM_MFMA_SWEEP(3) break;
+        default: NNLM_MFMA_SWEEP(4) break;
+        }
+#undef NNLM_MFMA_SWEEP
+        return;
+    }
     const int L = sweep_lanes_per_column(a.ncols);
     const int rneed = (h->k + L - 1) / L;
     if (L == 4) launch_sweep_l<2, 4>((rneed + 1) / 2, method, a, h->stream);      // R = 2..16, k <= 64
