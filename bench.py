@@ -40,14 +40,13 @@ def make_inputs(n, m, k):
 
 
 def run_steps(h, steps, trace, first_index=0):
-    """`steps` outer iterations with the reference's trace cadence; returns the last mse (or None)."""
+    """`steps` outer iterations of the reference loop (src/nnmf.cpp:109-161) on the resident problem: W half-step,
+    H half-step, error block every `trace` iterations (+ the closing one), rel.tol = -1 so that no iteration is skipped.
+    This is nnlm_run(), the same code path nnlm_c_nnmf() takes after its upload.  Returns the last mse."""
     z = [0.0, 0.0, 0.0]
-    mse = None
-    for i in range(first_index, first_index + steps):
-        h.iterate(1, z, z, INNER, INNER_TOL, METHOD)
-        if trace > 0 and i % trace == 0:
-            mse = h.errors()[0]
-    return mse
+    r = h.run(z, z, steps, -1.0, 0, False, INNER, INNER_TOL, METHOD, trace if trace > 0 else 999999)
+    assert r["n_iteration"] == steps
+    return float(r["mse_error"][-1])
 
 
 def cpu_baseline(A, W0, H0, k, iters, trace):

@@ -128,6 +128,13 @@ int nnlm_half_step(nnlm_handle *h, int which, const double reg[3], unsigned inne
 /* n_iter outer iterations (W half-step then H half-step, src/nnmf.cpp:114-133), asynchronous. */
 int nnlm_iterate(nnlm_handle *h, unsigned n_iter, const double alpha[3], const double beta[3],
                  unsigned inner_max_iter, double inner_rel_tol, int method);
+/* The alternating loop of c_nnmf (reference src/nnmf.cpp:100-209) on the resident matrix and factors: same arguments,
+ * traces, stopping rule, warning and callbacks as nnlm_c_nnmf, without the upload.  nnlm_c_nnmf is
+ * create + set_matrix + set_factors + nnlm_run + get_factors; bench.py times this call. */
+int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta[3], unsigned max_iter, double rel_tol, int verbose,
+             int show_warning, unsigned inner_max_iter, double inner_rel_tol, int method, unsigned trace,
+             double *mse_error, double *mkl_error, double *target_error, double *average_epoch, int *n_trace,
+             unsigned *n_iteration, int *warned, const nnlm_callbacks *cb);
 /* Summed per-column sweeps since the last reset (total_raw_iter, src/nnmf.cpp:106,158); synchronises. */
 int nnlm_take_sweeps(nnlm_handle *h, long long *sweeps, int reset);
 /* Error block (src/nnmf.cpp:121-126,135-140): mse = mean((A-WH)^2), mkl_var = mean(-(A+eps)log(WH+eps)+WH)

@@ -23,7 +23,7 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     "nnlm_trace_capacity", "nnlm_c_nnmf", "nnlm_c_nnlm", "nnlm_create", "nnlm_destroy", "nnlm_last_error",
     "nnlm_abi_version", "nnlm_set_matrix", "nnlm_matrix_info", "nnlm_set_factors", "nnlm_get_factors",
-    "nnlm_half_step", "nnlm_iterate", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
+    "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
     "nnlm_shard_range", "nnlm_debug_partial",
 ]
@@ -86,6 +86,9 @@ def load():
     lib.nnlm_half_step.argtypes = [vp, C.c_int, dp, C.c_uint, C.c_double, C.c_int]
     lib.nnlm_iterate.restype = C.c_int
     lib.nnlm_iterate.argtypes = [vp, C.c_uint, dp, dp, C.c_uint, C.c_double, C.c_int]
+    lib.nnlm_run.restype = C.c_int
+    lib.nnlm_run.argtypes = [vp, dp, dp, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_int, C.c_uint,
+                             dp, dp, dp, dp, ip, C.POINTER(C.c_uint), ip, C.POINTER(Callbacks)]
     lib.nnlm_take_sweeps.restype = C.c_int
     lib.nnlm_take_sweeps.argtypes = [vp, C.POINTER(C.c_longlong), C.c_int]
     lib.nnlm_errors.restype = C.c_int
@@ -279,6 +282,21 @@ class Handle:
     def iterate(self, n_iter, alpha, beta, inner_max_iter, inner_rel_tol, method):
         a, b = _vec3(alpha), _vec3(beta)
         self._ck(self._lib.nnlm_iterate(self._h, int(n_iter), _dp(a), _dp(b), int(inner_max_iter), float(inner_rel_tol), int(method)))
+
+    def run(self, alpha, beta, max_iter, rel_tol, verbose, show_warning, inner_max_iter, inner_rel_tol, method, trace,
+            callbacks=None):
+        """The resident c_nnmf loop (reference src/nnmf.cpp:100-209); returns the traces as a dict."""
+        a, b = _vec3(alpha), _vec3(beta)
+        cap = self._lib.nnlm_trace_capacity(int(max_iter), int(trace) if int(trace) > 0 else 1)
+        mse, mkl, terr, ep = (np.zeros(cap) for _ in range(4))
+        n_trace, n_it, warned = C.c_int(0), C.c_uint(0), C.c_int(0)
+        self._ck(self._lib.nnlm_run(self._h, _dp(a), _dp(b), int(max_iter), float(rel_tol), int(verbose), int(bool(show_warning)),
+                                    int(inner_max_iter), float(inner_rel_tol), int(method), int(trace) & 0xFFFFFFFF, _dp(mse),
+                                    _dp(mkl), _dp(terr), _dp(ep), C.byref(n_trace), C.byref(n_it), C.byref(warned),
+                                    C.byref(callbacks) if callbacks is not None else None))
+        e = n_trace.value
+        return dict(mse_error=mse[:e].copy(), mkl_error=mkl[:e].copy(), target_error=terr[:e].copy(),
+                    average_epoch=ep[:e].copy(), n_iteration=int(n_it.value), warning=bool(warned.value))
 
     def take_sweeps(self, reset=True):
         v = C.c_longlong(0)

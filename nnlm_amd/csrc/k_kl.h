@@ -19,7 +19,8 @@
 #define KL_MAX_P (KL_THREADS * 64)
 
 struct KlArgs {
-    double *X;       // [KP][ldx] master of the factor being solved
+    const double *X; // [KP][ldx] master of the factor being solved, read
+    double *Xout;    // same layout, written (may alias X)
     int ldx;
     const double *Y; // [KP][ldy] master of the fixed factor (contraction index fastest)
     int ldy;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     unsigned long long mword = 0ull;
     if (a.mask) mword = a.mask[col];
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-    if (a.mask && ((mword & kmask) == kmask)) return; // all coordinates masked: column skipped, 0 sweeps
+    const bool skipcol = a.mask && ((mword & kmask) == kmask); // all coordinates masked: 0 sweeps, values copied through
 
     if (tid < 64) xs[tid] = (tid < k) ? a.X[(size_t)tid * a.ldx + col] : 0.0;
     __syncthreads();
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     double rel = 1.0 + a.rel_tol;
     unsigned t = 0;
     int par = 0;
-    for (; t < a.max_iter && rel > a.rel_tol; t++) {
+    for (; !skipcol && t < a.max_iter && rel > a.rel_tol; t++) {
         rel = 0.0;
         for (int q = 0; q < k; q++) {
             if ((mword >> q) & 1ull) continue;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     __syncthreads();
     if (tid < k) {
         const double xv = xs[tid];
-        a.X[(size_t)tid * a.ldx + col] = xv;
+        a.Xout[(size_t)tid * a.ldx + col] = xv;
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)tid * a.op_ld + col] = xv;
             else ((float *)a.op)[(size_t)tid * a.op_ld + col] = (float)xv;

@@ -33,7 +33,8 @@
 typedef double f64x8 __attribute__((ext_vector_type(8)));
 
 struct SweepArgs {
-    double *X;          // [KPx][ldx] master copy of the factor being solved (row q, column index fastest)
+    const double *X;    // [KPx][ldx] master copy of the factor being solved (row q, column index fastest), read
+    double *Xout;       // same layout, written (may alias X; a different buffer lets a half-step run speculatively)
     int ldx;
     const double *Graw; // [KPg][KPg] Gram of the other factor (no edits applied yet)
     int KPg;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                 const int q = L * r + sub;
                 if (r < R && q < k) {
                     const double xv = x[c][e];
-                    a.X[(size_t)q * a.ldx + col] = xv;
+                    a.Xout[(size_t)q * a.ldx + col] = xv;
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
                         else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
                 const int q = 4 * b + lg;
                 if (q < k) {
                     const double xv = x[b];
-                    a.X[(size_t)q * a.ldx + col] = xv;
+                    a.Xout[(size_t)q * a.ldx + col] = xv;
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
                         else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;

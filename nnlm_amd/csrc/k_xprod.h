@@ -70,7 +70,9 @@ __device__ static inline int strided_count(int wave, int cnt) { return (wave < c
 // swizzle is applied to the per-lane GLOBAL source address (cdna_hip_programming.md rule 21).
 // Wave w owns image rows (columns j) [16w, 16w+16): one M-tile x NKQ N-tiles.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NKQ>
+// EXP: ablation switches for scripts/exp/xprod_exp.hip only (0 in the product): bit0 load the factor image only for the
+// first two stages, bit1 skip the MFMA phase, bit2 load the A image only for the first two stages.
+template <typename T, int NKQ, int EXP = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__restrict__ A, int lda,
                                                                  const T *__restrict__ Yop, int ldy,
                                                                  double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -101,13 +103,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     }
 
     auto issue = [&](int st, unsigned char *buf) {
-        const size_t i0 = (size_t)st * CE;
+        const size_t i0 = (size_t)(((EXP & 5) == 5 && st > st0 + 1) ? st0 : st) * CE;
 #pragma unroll
         for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
             const int row = 4 * t + lg;
             const int s = l15 ^ (row & 15);
-            glds16(A + (size_t)(j0 + row) * lda + i0 + s * EPV, buf + t * 1024);
+            const size_t ia = (size_t)(((EXP & 4) && st > st0 + 1) ? st0 : st) * CE; // EXP: re-read a cached stage
+            glds16(A + (size_t)(j0 + row) * lda + ((EXP & 4) ? ia : i0) + s * EPV, buf + t * 1024);
         }
+        if ((EXP & 1) && st > st0 + 1) return;
 #pragma unroll
         for (int t = wave; t < KP / 4; t += XPROD_WAVES) {
             const int row = 4 * t + lg;
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     };
 
     // loads THIS wavefront issues per stage (A image: 32 instructions over 8 waves; factor image: KP/4 instructions)
-    const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, KP / 4);
+    int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, KP / 4);
+    if (EXP & 1) per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES;
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     int since_flush = 0;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         wait_vmcnt((st + 1 < st1) ? per_stage : 0);
         __builtin_amdgcn_s_barrier();
         if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        if (EXP & 2) continue;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int phys = ((lg + 4 * kk) ^ l15) * 16;

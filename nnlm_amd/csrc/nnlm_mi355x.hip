@@ -44,7 +44,10 @@ struct ProfRec {
 struct nnlm_handle {
     int device = 0;
     int prec = NNLM_PREC_F32;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main: cross products, solvers
+    hipStream_t stream_g = nullptr; // Gram of the fixed factor, concurrent with the A-streaming cross product
+    hipStream_t stream_e = nullptr; // error block, concurrent with the (speculative) next W half-step
+    hipEvent_t ev_factor = nullptr, ev_gram = nullptr, ev_hdone = nullptr, ev_err = nullptr, ev_xdone = nullptr;
     std::string err;
 
     // problem
@@ -57,8 +60,11 @@ struct nnlm_handle {
 
     // factors
     int k = 0, NKQ = 0, KP = 0, KP8 = 0;
-    double *W64 = nullptr, *H64 = nullptr;        // [KP][npad], [KP][mpad]
-    void *Wop = nullptr, *Hop = nullptr;          // T [KP][npad] (aliases W64 in f64 mode), T [mpad][KP]
+    double *W64 = nullptr, *H64 = nullptr;        // [KP][npad], [KP][mpad]  (W64 = W64b[wcur])
+    void *Wop = nullptr, *Hop = nullptr;          // T [KP][npad] (aliases W64 in f64 mode), T [mpad][KP]  (Wop = Wopb[wcur])
+    double *W64b[2] = {nullptr, nullptr};         // W is double buffered: every W half-step writes the other buffer, so a
+    void *Wopb[2] = {nullptr, nullptr};           // speculative half-step can be dropped and the error block can read W_i
+    int wcur = 0;
     float *Hkq = nullptr;                         // fp32 [KP][mpad] copy of H, refreshed by nnlm_errors (f32 mode)
     unsigned long long *Wmask = nullptr, *Hmask = nullptr; // per column bitmask, or null
     bool has_wmask = false, has_hmask = false;
@@ -73,7 +79,9 @@ struct nnlm_handle {
     double *partials = nullptr;
     size_t partials_elems = 0;
     double *scal = nullptr;              // 16 doubles of reduction results
-    unsigned long long *sweeps = nullptr;
+    unsigned long long *sweeps = nullptr; // [2] device counters; sw_active = the one the current trace window sums into
+    int sw_active = 0;
+    double *host_res = nullptr;           // pinned: 8 reduction results + sweep counter of the asynchronous error block
 
     // multi-GPU
     int rank = 0, nranks = 1;
@@ -113,28 +121,36 @@ struct ProfScope {
     nnlm_handle *h;
     ProfRec r;
     bool on;
-    ProfScope(nnlm_handle *h_, int id) : h(h_), on(h_->prof)
+    hipStream_t st;
+    ProfScope(nnlm_handle *h_, int id, hipStream_t st_ = nullptr) : h(h_), on(h_->prof), st(st_ ? st_ : h_->stream)
     {
         if (on) {
             r.id = id;
             hipEventCreate(&r.e0);
             hipEventCreate(&r.e1);
-            hipEventRecord(r.e0, h->stream);
+            hipEventRecord(r.e0, st);
         }
     }
     ~ProfScope()
     {
         if (on) {
-            hipEventRecord(r.e1, h->stream);
+            hipEventRecord(r.e1, st);
             h->recs.push_back(r);
         }
     }
 };
 
+static void sync_all(nnlm_handle *h)
+{
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->stream_g) hipStreamSynchronize(h->stream_g);
+    if (h->stream_e) hipStreamSynchronize(h->stream_e);
+}
+
 static void prof_collect(nnlm_handle *h)
 {
     if (h->recs.empty()) return;
-    hipStreamSynchronize(h->stream);
+    sync_all(h);
     for (auto &r : h->recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -207,23 +223,37 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     nnlm_handle *h = new nnlm_handle();
     h->device = device;
     h->prec = precision;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_g, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_factor, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gram, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_hdone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_err, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_xdone, hipEventDisableTiming) != hipSuccess) {
         delete h;
-        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipStreamCreate failed");
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: stream/event creation failed");
     }
-    if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
-    hipMemsetAsync(h->sweeps, 0, sizeof(unsigned long long), h->stream);
+    hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
+    hipStreamSynchronize(h->stream);
     *out = h;
     return NNLM_OK;
 }
 
 static void free_factors(nnlm_handle *h)
 {
-    if (h->Wop && h->Wop != (void *)h->W64) hipFree(h->Wop);
-    hipFree(h->W64);
+    for (int i = 0; i < 2; i++) {
+        if (h->Wopb[i] && h->Wopb[i] != (void *)h->W64b[i]) hipFree(h->Wopb[i]);
+        hipFree(h->W64b[i]);
+        h->W64b[i] = nullptr;
+        h->Wopb[i] = nullptr;
+    }
+    h->wcur = 0;
     hipFree(h->H64);
     hipFree(h->Hop);
     hipFree(h->Hkq);
@@ -260,12 +290,20 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    sync_all(h);
     prof_collect(h);
     free_factors(h);
     free_matrix(h);
     hipFree(h->scal);
     hipFree(h->sweeps);
+    hipHostFree(h->host_res);
+    if (h->ev_factor) hipEventDestroy(h->ev_factor);
+    if (h->ev_gram) hipEventDestroy(h->ev_gram);
+    if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
+    if (h->ev_err) hipEventDestroy(h->ev_err);
+    if (h->ev_xdone) hipEventDestroy(h->ev_xdone);
+    if (h->stream_g) hipStreamDestroy(h->stream_g);
+    if (h->stream_e) hipStreamDestroy(h->stream_e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -430,7 +468,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
     if (k > NNLM_KQ_MAX) return fail(h, NNLM_ERR_UNSUPPORTED, "nnlm_set_factors: rank k=%d > %d is not supported by this build", k, NNLM_KQ_MAX);
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sync_all(h);
     if (k != h->k) {
         free_factors(h);
         h->k = k;
@@ -438,10 +476,16 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         h->KP = 16 * h->NKQ;
         h->KP8 = round_up_i(k, 8);
         const size_t es = esize(h);
-        HIPCHK(h, hipMalloc(&h->W64, (size_t)h->KP * h->npad * 8));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(h, hipMalloc(&h->W64b[i], (size_t)h->KP * h->npad * 8));
+            HIPCHK(h, hipMemset(h->W64b[i], 0, (size_t)h->KP * h->npad * 8));
+            if (h->prec == NNLM_PREC_F64) h->Wopb[i] = h->W64b[i];
+            else {
+                HIPCHK(h, hipMalloc(&h->Wopb[i], (size_t)h->KP * h->npad * es));
+                HIPCHK(h, hipMemset(h->Wopb[i], 0, (size_t)h->KP * h->npad * es));
+            }
+        }
         HIPCHK(h, hipMalloc(&h->H64, (size_t)h->KP * h->mpad * 8));
-        if (h->prec == NNLM_PREC_F64) h->Wop = h->W64;
-        else HIPCHK(h, hipMalloc(&h->Wop, (size_t)h->KP * h->npad * es));
         HIPCHK(h, hipMalloc(&h->Hop, (size_t)h->mpad * h->KP * es + 4096));
         if (h->prec == NNLM_PREC_F32) HIPCHK(h, hipMalloc(&h->Hkq, (size_t)h->KP * h->mpad * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * 8));
@@ -456,6 +500,11 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         HIPCHK(h, hipMalloc(&h->red, ((size_t)h->KP * h->KP + (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad)) * 8));
         h->Graw = h->red;
     }
+    h->wcur = 0;
+    h->W64 = h->W64b[0];
+    h->Wop = h->Wopb[0];
+    h->sw_active = 0;
+    HIPCHK(h, hipMemset(h->sweeps, 0, 2 * sizeof(unsigned long long)));
     const int KP = h->KP, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
     // host-side repack into the padded resident layouts (k*(n+m) elements: negligible)
     std::vector<double> w64((size_t)KP * npad, 0.0), h64((size_t)KP * mpad, 0.0);
@@ -498,7 +547,7 @@ extern "C" int nnlm_get_factors(nnlm_handle *h, double *W, double *H)
 {
     if (!h || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_get_factors: no factors set");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sync_all(h);
     const int k = h->k, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
     if (W) {
         std::vector<double> w64((size_t)h->KP * npad);
@@ -552,13 +601,13 @@ static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, in
     int nb = (c_end - c_begin + GRAM_COLS_PER_BLOCK - 1) / GRAM_COLS_PER_BLOCK;
     if (nb < 1) nb = 1;
     switch (h->NKQ) {
-    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
     }
     const int KP = h->KP;
-    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
+    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream_g>>>(h->gslabs, nb, KP, h->Graw);
     *nslabs = nb;
 }
 
@@ -692,7 +741,16 @@ static void launch_na_gram(nnlm_handle *h, const uint32_t *bits, int words, int 
 }
 
 // KL methods: no Gram, no cross product -- one block per column streams the column of A and the fixed factor.
-static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method)
+// After a W half-step has been enqueued into the alternate buffers: make them current.
+static void swap_w(nnlm_handle *h)
+{
+    h->wcur ^= 1;
+    h->W64 = h->W64b[h->wcur];
+    h->Wop = h->Wopb[h->wcur];
+}
+
+static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
+                        bool speculative)
 {
     if (h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods are not sharded across GPUs in this build");
     KlArgs a;
@@ -702,23 +760,23 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     a.r2 = reg[2];
     a.max_iter = inner_max_iter;
     a.rel_tol = inner_rel_tol;
-    a.sweeps = h->sweeps;
+    a.sweeps = h->sweeps + (speculative ? (h->sw_active ^ 1) : h->sw_active);
     a.A = h->A;
     a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
     if (which == 1) {
-        a.X = h->H64; a.ldx = h->mpad; a.Y = h->W64; a.ldy = h->npad;
+        a.X = h->H64; a.Xout = h->H64; a.ldx = h->mpad; a.Y = h->W64; a.ldy = h->npad;
         a.a_col_stride = (size_t)h->npad; a.a_i_stride = 1;
         a.bits = h->any_missing ? h->miss : nullptr; a.words = h->npad / 32;
         a.p = h->n; a.ncols = h->m;
         a.mask = h->has_hmask ? h->Hmask : nullptr;
         a.op = h->Hop; a.op_mode = 2; a.op_ld = h->KP;
     } else {
-        a.X = h->W64; a.ldx = h->npad; a.Y = h->H64; a.ldy = h->mpad;
+        a.X = h->W64; a.Xout = h->W64b[h->wcur ^ 1]; a.ldx = h->npad; a.Y = h->H64; a.ldy = h->mpad;
         a.a_col_stride = 1; a.a_i_stride = (size_t)h->npad;
         a.bits = h->any_missing ? h->missT : nullptr; a.words = h->mpad / 32;
         a.p = h->m; a.ncols = h->n;
         a.mask = h->has_wmask ? h->Wmask : nullptr;
-        a.op = h->Wop; a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1; a.op_ld = h->npad;
+        a.op = h->Wopb[h->wcur ^ 1]; a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1; a.op_ld = h->npad;
     }
     if (a.p > KL_MAX_P) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods support a contraction length up to %d (got %d)", KL_MAX_P, a.p);
     {
@@ -727,16 +785,19 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         else launch_kl<float>(method, a, h->stream);
     }
     HIPCHK(h, hipGetLastError());
+    if (which == 0 && !speculative) swap_w(h);
     return NNLM_OK;
 }
 
+// speculative (W half-step only): the result goes to the alternate W buffers and the alternate sweep counter and is
+// NOT made current; the caller accepts it later with swap_w() / sw_active ^= 1, or simply drops it.
 static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
-                     bool partial_only = false)
+                     bool partial_only = false, bool speculative = false)
 {
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
     HIPCHK(h, hipSetDevice(h->device));
-    if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method);
+    if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
     if (h->any_missing && h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
     if (h->any_missing && !h->Gcols) { // NA path workspaces, on first use
         const int big = h->npad > h->mpad ? h->npad : h->mpad;
@@ -744,16 +805,21 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         HIPCHK(h, hipMalloc(&h->Gcols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * h->KP * 8));
     }
     const HalfPlan p = plan_half(h, which, h->rank, h->nranks);
+    // The fixed factor is final once everything already on the main stream has run: the Gram kernels (stream_g) start
+    // there and overlap the A-streaming cross product (the xprod launch leaves 19 of 256 CUs idle at config 2).
+    HIPCHK(h, hipEventRecord(h->ev_factor, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_g, h->ev_factor, 0));
     // 1. cross product slabs
     {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
         if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
         else launch_xprod_nkq<float>(h, which, p);
     }
+    if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream)); // the error block starts once A is no longer streamed
     // 2. Gram of the fixed factor over this rank's contraction slab
     int gslabs = 0;
     {
-        ProfScope ps(h, P_GRAM);
+        ProfScope ps(h, P_GRAM, h->stream_g);
         const int CE = (which == 1) ? XPROD_ROWB / (int)esize(h) : XPROD_NT_ROWS;
         int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
         const int lim = (which == 1) ? h->n : h->m;
@@ -762,6 +828,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs);
         else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs);
     }
+    HIPCHK(h, hipEventRecord(h->ev_gram, h->stream_g));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gram, 0));
     // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer and sum it over ranks: ONE all-reduce
     const bool sharded = h->nranks > 1;
     if (sharded) {
@@ -788,9 +856,10 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         a.r2 = reg[2];
         a.max_iter = inner_max_iter;
         a.rel_tol = inner_rel_tol;
-        a.sweeps = h->sweeps;
+        a.sweeps = h->sweeps + (speculative ? (h->sw_active ^ 1) : h->sw_active);
         if (which == 1) {
             a.X = h->H64;
+            a.Xout = h->H64;
             a.ldx = h->mpad;
             a.ldc = h->mpad;
             a.slab_stride = (size_t)h->KP * h->mpad;
@@ -801,12 +870,13 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             a.op_ld = h->KP;
         } else {
             a.X = h->W64;
+            a.Xout = h->W64b[h->wcur ^ 1];
             a.ldx = h->npad;
             a.ldc = h->npad;
             a.slab_stride = (size_t)h->KP * h->npad;
             a.ncols = h->n;
             a.mask = h->has_wmask ? h->Wmask : nullptr;
-            a.op = h->Wop;
+            a.op = h->Wopb[h->wcur ^ 1];
             a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1;
             a.op_ld = h->npad;
         }
@@ -824,6 +894,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             launch_sweep(h, method, a);
     }
     HIPCHK(h, hipGetLastError());
+    if (which == 0 && !speculative) swap_w(h);
     return NNLM_OK;
 }
 
@@ -851,7 +922,7 @@ extern "C" int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, doub
         const size_t cnt = (size_t)h->KP * ld;
         slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, q.S, cnt, h->red + (size_t)h->KP * h->KP);
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sync_all(h);
     const int KP = h->KP, k = h->k;
     const int cols = (which == 1) ? h->m : h->n;
     std::vector<double> buf((size_t)KP * KP + (size_t)KP * ld);
@@ -882,8 +953,8 @@ extern "C" int nnlm_take_sweeps(nnlm_handle *h, long long *sweeps, int reset)
     if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_take_sweeps: handle is NULL");
     HIPCHK(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    HIPCHK(h, hipMemcpyAsync(&v, h->sweeps, sizeof v, hipMemcpyDeviceToHost, h->stream));
-    if (reset) HIPCHK(h, hipMemsetAsync(h->sweeps, 0, sizeof v, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&v, h->sweeps + h->sw_active, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    if (reset) HIPCHK(h, hipMemsetAsync(h->sweeps + h->sw_active, 0, sizeof v, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (sweeps) *sweeps = (long long)v;
     return NNLM_OK;
@@ -893,51 +964,76 @@ extern "C" int nnlm_sync(nnlm_handle *h)
 {
     if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_sync: handle is NULL");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sync_all(h);
+    HIPCHK(h, hipGetLastError());
     return NNLM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // error block
 // ---------------------------------------------------------------------------------------------
-extern "C" int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double pen[6])
+// Enqueue the error block on stream `st` for the CURRENT factors (pointers captured now); the 8 sums and, when
+// `with_sweeps`, the active sweep counter land in the pinned host_res[0..8]; ev_err fires when they are there.
+static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps)
 {
-    if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_errors: matrix and factors must be set first");
-    HIPCHK(h, hipSetDevice(h->device));
     const int k4 = round_up_i(h->k, 4);
     {
-        ProfScope ps(h, P_ERRORS);
+        ProfScope ps(h, P_ERRORS, st);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
         size_t nb;
         if (h->prec == NNLM_PREC_F64) {
             dim3 grid(h->npad / ERR_TILE, h->mpad / ERR_TILE);
             nb = (size_t)grid.x * grid.y;
-            errors_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
+            errors_kernel<double><<<grid, 256, 0, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
         } else {
             dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
             nb = (size_t)grid.x * grid.y;
             const int k2 = round_up_i(h->k, 2);
             const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
+            hipFuncSetAttribute((const void *)errors_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             const size_t cnt = (size_t)h->KP * h->mpad;
-            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
-            errors_f32_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials);
+            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(h->H64, cnt, h->Hkq);
+            errors_f32_kernel<<<grid, 256, lds, st>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials);
         }
-        reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, nb, 2, h->scal);
+        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, nb, 2, h->scal);
     }
     const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
-    penalty_kernel<<<nbw, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->partials);
-    reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
-    penalty_kernel<<<nbh, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, h->partials);
-    reduce_partials_kernel<<<1, 256, 0, h->stream>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
-    double out[8];
-    HIPCHK(h, hipMemcpyAsync(out, h->scal, sizeof out, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    penalty_kernel<<<nbw, 256, 0, st>>>(h->W64, h->npad, h->n, h->k, h->partials);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
+    penalty_kernel<<<nbh, 256, 0, st>>>(h->H64, h->mpad, h->m, h->k, h->partials);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
+    HIPCHK(h, hipMemcpyAsync(h->host_res, h->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (with_sweeps) {
+        HIPCHK(h, hipMemcpyAsync(h->host_res + 8, h->sweeps + h->sw_active, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemsetAsync(h->sweeps + h->sw_active, 0, sizeof(unsigned long long), st));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_err, st));
     HIPCHK(h, hipGetLastError());
-    if (mse) *mse = out[0] / h->n_non_missing;
-    if (mkl_var) *mkl_var = out[1] / h->n_non_missing;
-    if (pen)
-        for (int i = 0; i < 6; i++) pen[i] = out[2 + i];
     return NNLM_OK;
+}
+
+static int errors_collect(nnlm_handle *h, double *mse, double *mkl_var, double pen[6], long long *raw_sweeps)
+{
+    HIPCHK(h, hipEventSynchronize(h->ev_err));
+    if (mse) *mse = h->host_res[0] / h->n_non_missing;
+    if (mkl_var) *mkl_var = h->host_res[1] / h->n_non_missing;
+    if (pen)
+        for (int i = 0; i < 6; i++) pen[i] = h->host_res[2 + i];
+    if (raw_sweeps) {
+        unsigned long long v;
+        memcpy(&v, h->host_res + 8, sizeof v);
+        *raw_sweeps = (long long)v;
+    }
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double pen[6])
+{
+    if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_errors: matrix and factors must be set first");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = errors_launch(h, h->stream, false);
+    if (rc != NNLM_OK) return rc;
+    return errors_collect(h, mse, mkl_var, pen, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1093,6 +1189,118 @@ static double penalties(double terr, const double pen[6], double N, const double
     return terr;
 }
 
+// The alternating loop of c_nnmf (reference src/nnmf.cpp:100-209) on a resident handle: matrix and factors are already in
+// HBM.  Semantics are the reference's, iteration by iteration.  What is MI355X-specific is the schedule at a trace
+// iteration: the error block runs on its own stream (HBM/MFMA bound) while the NEXT iteration's W half-step is enqueued
+// speculatively on the main stream (its sweep is VALU/matrix-core bound and touches no HBM to speak of) into the second
+// W buffer; when the host has the error block's result it either accepts the speculative half-step (swap buffers) or,
+// if the stopping rule fired, drops it -- W_i is still intact in the first buffer.
+extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta[3], unsigned max_iter, double rel_tol, int verbose,
+                        int show_warning, unsigned inner_max_iter, double inner_rel_tol, int method, unsigned trace,
+                        double *mse_error, double *mkl_error, double *target_error, double *average_epoch, int *n_trace,
+                        unsigned *n_iteration, int *warned, const nnlm_callbacks *cb)
+{
+    if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_run: matrix and factors must be set first");
+    if (!alpha || !beta || !mse_error || !mkl_error || !target_error || !average_epoch || !n_trace || !n_iteration || !warned)
+        return fail(h, NNLM_ERR_ARG, "nnlm_run: NULL argument");
+    if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+#define CHK(x)                  \
+    do {                        \
+        rc = (x);               \
+        if (rc != NNLM_OK) {    \
+            g_last_error = h->err; \
+            return rc;          \
+        }                       \
+    } while (0)
+
+    if (trace < 1) trace = 1; // src/nnmf.cpp:53
+    const unsigned err_len = nnlm_trace_capacity(max_iter, trace);
+    const double N = h->n_non_missing;
+    const int n = h->n, m = h->m;
+    for (unsigned e = 0; e < err_len; e++) mkl_error[e] = h->kl_const; // src/nnmf.cpp:70,73
+
+    if (verbose == 2) { // src/nnmf.cpp:100-104
+        cb_print(cb, "\n%10s | %10s | %10s | %10s | %10s\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
+        cb_print(cb, "--------------------------------------------------------------\n");
+    }
+
+    double rel_err = rel_tol + 1, terr_last = 1e99;
+    unsigned i = 0, i_e = 0;
+    auto book = [&](unsigned it, double mse, double kl, const double pen[6], long long raw) {
+        mse_error[i_e] = mse;
+        mkl_error[i_e] += kl;
+        average_epoch[i_e] = (double)raw / (double)(n + m); // src/nnmf.cpp:145
+        double t = (method < 3) ? 0.5 * mse_error[i_e] : mkl_error[i_e];
+        t = penalties(t, pen, N, alpha, beta);
+        target_error[i_e] = t;
+        rel_err = 2 * (terr_last - t) / (terr_last + t + NNLM_TINY); // src/nnmf.cpp:153
+        terr_last = t;
+        if (verbose == 2) cb_print(cb, "%10d | %10.4f | %10.4f | %10.4f | %10.g\n", it + 1, mse_error[i_e], mkl_error[i_e], t, rel_err);
+        ++i_e;
+    };
+
+    bool spec_pending = false; // the W half-step of iteration i is already enqueued (speculatively)
+    for (; i < max_iter && std::fabs(rel_err) > rel_tol; i++) { // src/nnmf.cpp:109
+        if (cb && cb->check_interrupt && cb->check_interrupt(cb->ctx)) { // src/nnmf.cpp:111
+            sync_all(h);
+            g_last_error = "interrupted";
+            return NNLM_ERR_INTERRUPT;
+        }
+        if (verbose == 1 && cb && cb->progress) cb->progress(cb->ctx, i + 1, max_iter); // src/nnmf.cpp:112
+        if (spec_pending) { // accept: its buffers and its sweep counter become the current ones
+            swap_w(h);
+            h->sw_active ^= 1;
+            spec_pending = false;
+        } else
+            CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method)); // update W, src/nnmf.cpp:131
+        CHK(half_step(h, 1, beta, inner_max_iter, inner_rel_tol, method));      // update H, src/nnmf.cpp:133
+        if (i % trace == 0) {                                                   // src/nnmf.cpp:135-160
+            HIPCHK(h, hipEventRecord(h->ev_hdone, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_hdone, 0));
+            if (i + 1 < max_iter && h->nranks == 1 && method < 3) {
+                // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below); the error
+                // block (one more pass over A) is held back until that half-step's own pass over A is done, so the
+                // two HBM streams do not collide and the error block overlaps the compute-bound sweep instead
+                CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true));
+                HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
+                spec_pending = true;
+            }
+            CHK(errors_launch(h, h->stream_e, true)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            // H (and the fp32 copy the error kernel reads) must not be rewritten before the error block is done
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_err, 0));
+            double mse, kl, pen[6];
+            long long raw = 0;
+            CHK(errors_collect(h, &mse, &kl, pen, &raw));
+            book(i, mse, kl, pen, raw);
+        }
+    }
+    if (spec_pending) { // the stopping rule fired: drop the speculative half-step (W_i is untouched) and its sweep count
+        HIPCHK(h, hipMemsetAsync(h->sweeps + (h->sw_active ^ 1), 0, sizeof(unsigned long long), h->stream));
+        spec_pending = false;
+    }
+    if ((unsigned)(i - 1) % trace != 0) { // src/nnmf.cpp:164 (unsigned arithmetic)
+        double mse, kl, pen[6];
+        long long raw = 0;
+        CHK(nnlm_errors(h, &mse, &kl, pen));
+        CHK(nnlm_take_sweeps(h, &raw, 1));
+        book(i, mse, kl, pen, raw);
+    }
+
+    if (verbose == 2) { // src/nnmf.cpp:194-198
+        cb_print(cb, "--------------------------------------------------------------\n");
+        cb_print(cb, "%10s | %10s | %10s | %10s | %10s\n\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
+    }
+    sync_all(h);
+    HIPCHK(h, hipGetLastError());
+    *n_trace = (int)i_e;
+    *n_iteration = i;
+    *warned = (show_warning && rel_err > rel_tol) ? 1 : 0; // src/nnmf.cpp:208
+    if (*warned && cb && cb->warning) cb->warning(cb->ctx, "Target tolerance not reached. Try a larger max.iter.");
+    return NNLM_OK;
+}
+
 extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const double *W_init, const double *H_init, const int *Wm,
                            const int *Hm, const double alpha[3], const double beta[3], unsigned max_iter, double rel_tol,
                            int n_threads, int verbose, int show_warning, unsigned inner_max_iter, double inner_rel_tol,
@@ -1112,20 +1320,7 @@ extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const doub
         nnlm_handle *h;
         ~Guard() { nnlm_destroy(h); }
     } guard{h};
-#define CHK(x)                                   \
-    do {                                         \
-        rc = (x);                                \
-        if (rc != NNLM_OK) {                     \
-            g_last_error = h->err;               \
-            return rc;                           \
-        }                                        \
-    } while (0)
-
-    if (trace < 1) trace = 1; // src/nnmf.cpp:53
-    const unsigned err_len = nnlm_trace_capacity(max_iter, trace);
     CHK(nnlm_set_matrix(h, A, n, m));
-    const double N = h->n_non_missing;
-    for (unsigned e = 0; e < err_len; e++) mkl_error[e] = h->kl_const; // src/nnmf.cpp:70,73
 
     // default init, src/nnmf.cpp:82-98: W.randu(k,n)*0.01 drawn column-major, W first, masked entries zeroed
     std::vector<double> Wi, Hi;
@@ -1151,54 +1346,8 @@ extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const doub
         H_init = Hi.data();
     }
     CHK(nnlm_set_factors(h, k, W_init, H_init, Wm, Hm));
-
-    if (verbose == 2) { // src/nnmf.cpp:100-104
-        cb_print(cb, "\n%10s | %10s | %10s | %10s | %10s\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
-        cb_print(cb, "--------------------------------------------------------------\n");
-    }
-
-    double rel_err = rel_tol + 1, terr_last = 1e99;
-    unsigned i = 0, i_e = 0;
-    auto error_block = [&](unsigned it) -> int {
-        double mse, kl, pen[6];
-        long long raw = 0;
-        int r = nnlm_errors(h, &mse, &kl, pen);
-        if (r != NNLM_OK) return r;
-        r = nnlm_take_sweeps(h, &raw, 1); // total_raw_iter, reset to 0 (src/nnmf.cpp:158)
-        if (r != NNLM_OK) return r;
-        mse_error[i_e] = mse;
-        mkl_error[i_e] += kl;
-        average_epoch[i_e] = (double)raw / (double)(n + m); // src/nnmf.cpp:145
-        double t = (method < 3) ? 0.5 * mse_error[i_e] : mkl_error[i_e];
-        t = penalties(t, pen, N, alpha, beta);
-        target_error[i_e] = t;
-        rel_err = 2 * (terr_last - t) / (terr_last + t + NNLM_TINY); // src/nnmf.cpp:153
-        terr_last = t;
-        if (verbose == 2) cb_print(cb, "%10d | %10.4f | %10.4f | %10.4f | %10.g\n", it + 1, mse_error[i_e], mkl_error[i_e], t, rel_err);
-        ++i_e;
-        return NNLM_OK;
-    };
-
-    for (; i < max_iter && std::fabs(rel_err) > rel_tol; i++) { // src/nnmf.cpp:109
-        if (cb && cb->check_interrupt && cb->check_interrupt(cb->ctx)) { // src/nnmf.cpp:111
-            g_last_error = "interrupted";
-            return NNLM_ERR_INTERRUPT;
-        }
-        if (verbose == 1 && cb && cb->progress) cb->progress(cb->ctx, i + 1, max_iter); // src/nnmf.cpp:112
-        CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method));
-        CHK(half_step(h, 1, beta, inner_max_iter, inner_rel_tol, method));
-        if (i % trace == 0) CHK(error_block(i));
-    }
-    if ((unsigned)(i - 1) % trace != 0) CHK(error_block(i)); // src/nnmf.cpp:164 (unsigned arithmetic)
-
-    if (verbose == 2) { // src/nnmf.cpp:194-198
-        cb_print(cb, "--------------------------------------------------------------\n");
-        cb_print(cb, "%10s | %10s | %10s | %10s | %10s\n\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
-    }
-    *n_trace = (int)i_e;
-    *n_iteration = i;
-    *warned = (show_warning && rel_err > rel_tol) ? 1 : 0; // src/nnmf.cpp:208
-    if (*warned && cb && cb->warning) cb->warning(cb->ctx, "Target tolerance not reached. Try a larger max.iter.");
+    CHK(nnlm_run(h, alpha, beta, max_iter, rel_tol, verbose, show_warning, inner_max_iter, inner_rel_tol, method, trace, mse_error,
+                 mkl_error, target_error, average_epoch, n_trace, n_iteration, warned, cb));
     CHK(nnlm_get_factors(h, W_out, H_out));
     return NNLM_OK;
 }
