@@ -53,7 +53,10 @@ template <int NT, bool HAS_MASK>
 __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
 {
     constexpr int KP = 16 * NT, NB = 4 * NT;
-    // Gz[b][t][g][l] = edited G[16t + l][4b + g], with the 4x4 diagonal blocks zeroed  (MFMA A operand of block b, tile t)
+    // Blocks are dealt to the NT accumulator tiles round-robin: block b lives in tile b % NT, accumulator register b / NT,
+    // so consecutive blocks sit in different tiles and the next block's chain only waits for ONE MFMA.
+    // coordinate of (tile t, accumulator row M) = 4*((M/4)*NT + t) + M%4.
+    // Gz[b][t][g][l] = edited G[coord(t, l)][4b + g], with the 4x4 diagonal blocks zeroed  (MFMA A operand of block b, tile t)
     __shared__ __attribute__((aligned(16))) double Gz[NB * NT * 64];
     __shared__ __attribute__((aligned(16))) double G4[NB * 16]; // [b][s'][s] = edited G[4b + s'][4b + s]
     __shared__ __attribute__((aligned(16))) double rG[KP];      // 1 / G[q][q]
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
     };
     for (int e = tid; e < NB * NT * 64; e += 256) {
         const int b = e / (NT * 64), rem = e % (NT * 64), t = rem / 64, g = (rem % 64) / 16, l = rem % 16;
-        const int c = 16 * t + l, kc = 4 * b + g;
+        const int c = 4 * ((l >> 2) * NT + t) + (l & 3), kc = 4 * b + g;
         Gz[e] = (c < k && kc < k && (c >> 2) != b) ? edited(c, kc) : 0.0;
     }
     for (int e = tid; e < NB * 16; e += 256) {
@@ -88,20 +91,21 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
     bool act = in_range && !(a.mask && ((mword & kmask) == kmask)); // arma::all(mask.col(j)) -> column skipped
 
-    // element b of this lane's vectors <-> coordinate 4b + lg (block b); MFMA tile t = elements 4t..4t+3
-    // (f64 accumulator layout: reg r of tile t is row lg + 4r, i.e. coordinate 16t + 4r + lg = 4(4t + r) + lg).
-    // One 16-element vector per quantity so that the wave-uniform block index can address it (s_set_gpr_idx).
+    // element e = 4t + r of this lane's vectors <-> block b = r*NT + t <-> coordinate 4b + lg; MFMA tile t = elements
+    // 4t..4t+3 (f64 accumulator layout: reg r of tile t is row lg + 4r).  One 16-element vector per quantity so that the
+    // wave-uniform register index r can address it (s_set_gpr_idx).
     f64x16 x, mu;
 #pragma unroll
-    for (int b = 0; b < 16; b++) {
+    for (int e = 0; e < 16; e++) {
+        const int b = (e & 3) * NT + (e >> 2); // meaningful for e < 4*NT
         const int q = 4 * b + lg;
         double xv = 0.0, cv = 0.0;
-        if (b < NB && q < k) {
+        if (e < NB && q < k) {
             xv = a.X[(size_t)q * a.ldx + cc];
             for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)q * a.ldc + cc];
         }
-        x[b] = xv;
-        mu[b] = (b < NB && q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) : 0.0;
+        x[e] = xv;
+        mu[e] = (e < NB && q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) : 0.0;
     }
     const double *gzl = Gz + lane;                 // + (b*NT + t)*64
     const f64x2 *g4row = (const f64x2 *)(G4 + 4 * lg); // + 8*b : row lg of diagonal block b (this lane's coordinate)
@@ -121,18 +125,24 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
 
     // mu = (L1 - c) + G x : off-diagonal blocks on the matrix cores, diagonal blocks with 4 FMAs
 #pragma nounroll
-    for (int kb = 0; kb < nbk; kb++) {
-        const double xb = x[kb];
-        SWEEP_MFMA_RANK4(kb, xb)
-        double xs[4];
-        rows_allgather(xb, xs);
-        const f64x2 ga = g4row[8 * kb], gb = g4row[8 * kb + 1];
-        double add = mu[kb];
-        add = __builtin_fma(ga[0], xs[0], add);
-        add = __builtin_fma(ga[1], xs[1], add);
-        add = __builtin_fma(gb[0], xs[2], add);
-        add = __builtin_fma(gb[1], xs[3], add);
-        mu[kb] = add;
+    for (int r0 = 0; r0 < 4; r0++) {
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0++) {
+            const int kb = r0 * NT + t0;
+            if (kb < nbk) { // wave-uniform
+                const double xb = x[4 * t0 + r0];
+                SWEEP_MFMA_RANK4(kb, xb)
+                double xs[4];
+                rows_allgather(xb, xs);
+                const f64x2 ga = g4row[8 * kb], gb = g4row[8 * kb + 1];
+                double add = mu[4 * t0 + r0];
+                add = __builtin_fma(ga[0], xs[0], add);
+                add = __builtin_fma(ga[1], xs[1], add);
+                add = __builtin_fma(gb[0], xs[2], add);
+                add = __builtin_fma(gb[1], xs[3], add);
+                mu[4 * t0 + r0] = add;
+            }
+        }
     }
 
     int t_lane = 0;
@@ -141,8 +151,12 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
     while (t < a.max_iter && __any(act)) {
         int flag = (0.0 > tol) ? 1 : 0; // rel_err starts each sweep at 0: a negative rel_tol never stops
 #pragma nounroll
-        for (int b = 0; b < nbk; b++) {
-            const double mu_own = mu[b], x_own = x[b];
+        for (int r0 = 0; r0 < 4; r0++) {
+#pragma unroll
+          for (int t0 = 0; t0 < NT; t0++) {
+            const int b = r0 * NT + t0; // consecutive blocks, consecutive tiles
+            if (b >= nbk) continue;     // wave-uniform
+            const double mu_own = mu[4 * t0 + r0], x_own = x[4 * t0 + r0];
             double m[4], xs[4];
             rows_allgather(mu_own, m);
             rows_allgather(x_own, xs);
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
             // holds the next block's coordinate goes first
 #pragma unroll
             for (int u = 0; u < NT; u++) {
-                const int t2 = (u + 1) % NT; // static rotation; exact tile order is irrelevant for correctness
+                const int t2 = (t0 + 1 + u) % NT; // the tile of the NEXT block first: its chain waits for one MFMA only
                 f64x4 tile = f64x4{mu[4 * t2], mu[4 * t2 + 1], mu[4 * t2 + 2], mu[4 * t2 + 3]};
                 tile = __builtin_amdgcn_mfma_f64_16x16x4f64(gzl[(b * NT + t2) * 64], d_own, tile, 0, 0, 0);
                 mu[4 * t2] = tile[0];
@@ -198,8 +212,9 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
             mo = __builtin_fma(dd[2], gb[0], mo);
             mo = __builtin_fma(dd[3], gb[1], mo);
             mo = act ? mo : mu_own;
-            mu[b] = mo;
-            x[b] = x_new;
+            mu[4 * t0 + r0] = mo;
+            x[4 * t0 + r0] = x_new;
+          }
         }
         unsigned fl[4];
         rows_allgather_u32((unsigned)flag, fl);
@@ -214,11 +229,11 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
 
     if (in_range) {
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
+        for (int e = 0; e < NB; e++) {
             {
-                const int q = 4 * b + lg;
+                const int q = 4 * ((e & 3) * NT + (e >> 2)) + lg;
                 if (q < k) {
-                    const double xv = x[b];
+                    const double xv = x[e];
                     a.Xout[(size_t)q * a.ldx + col] = xv;
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
