@@ -150,9 +150,11 @@ int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_ms, long lo
 int nnlm_profile_reset(nnlm_handle *h);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated; each rank contracts its
- * slab of rows (H half-step) / columns (W half-step) and the partial [Gram | cross-product]
- * buffer is summed with ONE ncclAllReduce per half-step; the sweep then runs replicated.
+ * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated.  Per half-step each rank
+ * contracts its slab of rows (H half-step) / columns (W half-step); ONE ncclAllReduce sums the
+ * partial [Gram | cross-product] buffer; each rank then solves its own 1/N of the columns and ONE
+ * ncclAllGather returns the updated factor to every rank.  Error block: each rank reduces its
+ * share of A, two doubles are all-reduced.
  * ---------------------------------------------------------------------------------------- */
 #define NNLM_COMM_ID_BYTES 128
 int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */
@@ -166,6 +168,14 @@ int nnlm_shard_range(int n, int m, int precision, int which, int rank, int nrank
 /* Test hook: partial [Gram k x k | cross product k x cols] of this (virtual) rank's slab, column-major, before the
  * all-reduce and before the regularisation edits of src/update_with_missing.cpp:20-24. */
 int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out);
+
+/* Test hooks for virtual ranks (several handles in one process, nnlm_comm_init(h, NULL, r, P)): nnlm_debug_phase runs ONE
+ * phase of a sharded half-step -- 1: cross product + Gram of the rank's contraction slab folded into [G | C];
+ * 2: sweep of the rank's columns into its packed slab; 3: unpack of the gathered slabs -- and nnlm_debug_exchange does,
+ * through the host, what ncclAllReduce (stage 1) / ncclAllGather (stage 2) do between them on a real node. */
+int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const double reg[3], unsigned inner_max_iter,
+                     double inner_rel_tol, int method);
+int nnlm_debug_exchange(nnlm_handle **handles, int nranks, int which, int stage);
 
 #ifdef __cplusplus
 }

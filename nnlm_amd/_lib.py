@@ -25,7 +25,7 @@ EXPORTS = [
     "nnlm_abi_version", "nnlm_set_matrix", "nnlm_matrix_info", "nnlm_set_factors", "nnlm_get_factors",
     "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
-    "nnlm_shard_range", "nnlm_debug_partial",
+    "nnlm_shard_range", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
 ]
 
 
@@ -111,6 +111,10 @@ def load():
     lib.nnlm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
     lib.nnlm_debug_partial.restype = C.c_int
     lib.nnlm_debug_partial.argtypes = [vp, C.c_int, dp, dp]
+    lib.nnlm_debug_phase.restype = C.c_int
+    lib.nnlm_debug_phase.argtypes = [vp, C.c_int, C.c_int, dp, C.c_uint, C.c_double, C.c_int]
+    lib.nnlm_debug_exchange.restype = C.c_int
+    lib.nnlm_debug_exchange.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -328,6 +332,10 @@ class Handle:
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES) if unique_id is not None else None
         self._ck(self._lib.nnlm_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def debug_phase(self, which, phase, reg, inner_max_iter, inner_rel_tol, method):
+        r = _vec3(reg)
+        self._ck(self._lib.nnlm_debug_phase(self._h, int(which), int(phase), _dp(r), int(inner_max_iter), float(inner_rel_tol), int(method)))
+
     def debug_partial(self, which):
         cols = self.m if which == 1 else self.n
         G = np.zeros((self.k, self.k), order="F")
@@ -346,6 +354,12 @@ def shard_range(n, m, precision, which, rank, nranks):
     b, e = C.c_int(0), C.c_int(0)
     _check(load().nnlm_shard_range(int(n), int(m), int(precision), int(which), int(rank), int(nranks), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def debug_exchange(handles, which, stage):
+    """Host stand-in for ncclAllReduce (stage 1) / ncclAllGather (stage 2) between virtual ranks (test hook)."""
+    arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    _check(load().nnlm_debug_exchange(arr, len(handles), int(which), int(stage)))
 
 
 def comm_unique_id() -> bytes:

@@ -15,14 +15,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, int lda, const uint32_t *__restrict__ miss,
                                                      const double *__restrict__ W64, int ldw,
                                                      const double *__restrict__ H64, int ldh, int n, int m, int k4,
-                                                     double *__restrict__ partial)
+                                                     double *__restrict__ partial, int jt0)
 {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int ib = blockIdx.x * ERR_TILE + 32 * (wave & 1);
-    const int jb = blockIdx.y * ERR_TILE + 32 * (wave >> 1);
+    const int jb = (blockIdx.y + jt0) * ERR_TILE + 32 * (wave >> 1); // jt0: first j-tile of this rank's share (multi-GPU)
 
     acc_t acc[2][2];
 #pragma unroll
@@ -97,13 +97,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict__ A, int lda, const uint32_t *__restrict__ miss,
                                                          const float *__restrict__ Wf, int ldw,
                                                          const float *__restrict__ Hf, int ldh, int n, int m, int k2,
-                                                         double *__restrict__ partial)
+                                                         double *__restrict__ partial, int jt0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_err[];
     float *Ws = (float *)smem_err;               // [k2][128]
     float *Hs = Ws + (size_t)k2 * ERRF_TILE;      // [k2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * ERRF_TILE, j0 = blockIdx.y * ERRF_TILE;
+    const int i0 = blockIdx.x * ERRF_TILE, j0 = (blockIdx.y + jt0) * ERRF_TILE; // jt0: this rank's first j-tile
     const int l31 = lane & 31, lh = lane >> 5;
     const int ib = 64 * (wave & 1), jb = 64 * (wave >> 1);
 

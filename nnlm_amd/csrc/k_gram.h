@@ -105,3 +105,28 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restri
     for (int i = 0; i < nslabs; i++) s += slabs[(size_t)i * cnt + e];
     out[e] = s;
 }
+
+// Multi-GPU: scatter the all-gathered per-rank slabs of the updated factor back into the resident layouts.
+// packed [nranks][KP][cpr] (rank rr holds columns rr*cpr .. of the factor); X [KP][ldx] master; op = GEMM operand copy
+// (op_mode 1: [KP][op_ld] same layout as X, 2: [col][op_ld] kq fastest, 0: none), element type float or double.
+__global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KP, int cpr, int k,
+                                                           int ncols, double *__restrict__ X, int ldx, void *__restrict__ op,
+                                                           int op_mode, int op_ld, int op_f64)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_rank = (size_t)KP * cpr;
+    if (e >= per_rank * nranks) return;
+    const int rr = (int)(e / per_rank);
+    const int q = (int)((e % per_rank) / cpr), lc = (int)(e % cpr);
+    const int col = rr * cpr + lc;
+    if (q >= k || col >= ncols) return;
+    const double v = packed[e];
+    X[(size_t)q * ldx + col] = v;
+    if (op_mode == 1) {
+        if (op_f64) ((double *)op)[(size_t)q * op_ld + col] = v;
+        else ((float *)op)[(size_t)q * op_ld + col] = (float)v;
+    } else if (op_mode == 2) {
+        if (op_f64) ((double *)op)[(size_t)col * op_ld + q] = v;
+        else ((float *)op)[(size_t)col * op_ld + q] = (float)v;
+    }
+}

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
         }
     }
     if (lv) {
-        a.Xout[(size_t)lane * a.ldx + col] = x;
+        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = x;
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
             else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;

@@ -34,15 +34,18 @@ typedef double f64x8 __attribute__((ext_vector_type(8)));
 
 struct SweepArgs {
     const double *X;    // [KPx][ldx] master copy of the factor being solved (row q, column index fastest), read
-    double *Xout;       // same layout, written (may alias X; a different buffer lets a half-step run speculatively)
+    double *Xout;       // written: entry (q, col) goes to Xout[q*ldo + (col - ocol0)]  (may alias X; a different buffer
+                        // lets a half-step run speculatively; a packed per-rank slab feeds the multi-GPU all-gather)
     int ldx;
+    int ldo, ocol0;
+    int col0;           // first column this launch solves (columns col0 .. ncols-1)
     const double *Graw; // [KPg][KPg] Gram of the other factor (no edits applied yet)
     int KPg;
     const double *Cx;   // [nslabs][KPg][ldc] split-K partial cross products
     size_t slab_stride;
     int nslabs;
     int ldc;
-    int ncols;          // columns to solve
+    int ncols;          // END of the column range to solve (exclusive); all of X has at least this many columns
     int k;              // true rank
     double r0, r1, r2;  // L2, angle, L1 of this half-step (beta in the reference's update())
     const unsigned long long *mask; // [ncols] bit q set <=> entry (q, col) is masked; NULL = no mask
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
     __shared__ __attribute__((aligned(16))) f64x2 Gd[KPs];
     const int lane = threadIdx.x;
     const int sub = lane % L;
-    const int col = blockIdx.x * (64 / L) + lane / L;
+    const int col = a.col0 + blockIdx.x * (64 / L) + lane / L;
     const int k = a.k;
     sweep_load_gram<R, L>(Gp, Gd, a, lane, 64);
     __syncthreads();
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                 const int q = L * r + sub;
                 if (r < R && q < k) {
                     const double xv = x[c][e];
-                    a.Xout[(size_t)q * a.ldx + col] = xv;
+                    a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
                         else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
     for (int q = tid; q < KP; q += 256) rG[q] = 1.0 / ((q < k) ? edited(q, q) : 1.0);
     __syncthreads();
 
-    const int col = (blockIdx.x * 4 + wave) * 16 + l15;
+    const int col = a.col0 + (blockIdx.x * 4 + wave) * 16 + l15;
     const bool in_range = col < a.ncols;
     const int cc = in_range ? col : 0;
     unsigned long long mword = 0ull;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void sweep_scd_mfma_kernel(const SweepArgs a)
                 const int q = 4 * ((e & 3) * NT + (e >> 2)) + lg;
                 if (q < k) {
                     const double xv = x[e];
-                    a.Xout[(size_t)q * a.ldx + col] = xv;
+                    a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
                         else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;

@@ -86,6 +86,11 @@ struct nnlm_handle {
     // multi-GPU
     int rank = 0, nranks = 1;
     void *comm = nullptr;
+    bool sharded = false;       // nranks > 1, or a real 1-rank communicator (exercises the sharded code path on one GPU)
+    double *pack_send = nullptr; // [KP][cpr]: this rank's updated columns, contiguous for ncclAllGather
+    double *pack_all = nullptr;  // [nranks][KP][cpr]
+    size_t pack_elems = 0;
+    unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
     // profiling
     bool prof = false;
@@ -169,6 +174,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -184,9 +190,10 @@ static int rccl_load()
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return fail(nullptr, NNLM_ERR_COMM, "librccl lacks a required symbol");
     g_rccl.lib = lib;
     return NNLM_OK;
@@ -235,7 +242,8 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: stream/event creation failed");
     }
     if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess) {
+        hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
@@ -263,6 +271,10 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Cx);
     hipFree(h->gslabs);
     hipFree(h->red);
+    hipFree(h->pack_send);
+    hipFree(h->pack_all);
+    h->pack_send = h->pack_all = nullptr;
+    h->pack_elems = 0;
     hipFree(h->Yrow);
     hipFree(h->Gcols);
     h->red = h->Yrow = h->Gcols = nullptr;
@@ -297,6 +309,7 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipFree(h->scal);
     hipFree(h->sweeps);
     hipHostFree(h->host_res);
+    hipFree(h->sweeps_tmp);
     if (h->ev_factor) hipEventDestroy(h->ev_factor);
     if (h->ev_gram) hipEventDestroy(h->ev_gram);
     if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
@@ -752,7 +765,7 @@ static void swap_w(nnlm_handle *h)
 static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
                         bool speculative)
 {
-    if (h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods are not sharded across GPUs in this build");
+    if (h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods are not sharded across GPUs in this build");
     KlArgs a;
     a.k = h->k;
     a.r0 = reg[0];
@@ -789,16 +802,29 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     return NNLM_OK;
 }
 
+// Phases of a sharded half-step (test hooks drive virtual ranks phase by phase; production runs PH_ALL):
+//   PH_A   cross product + Gram over this rank's contraction slab, folded into the [G | C] buffer (before the all-reduce)
+//   PH_B   sweep of this rank's columns into the packed slab (after the all-reduce, before the all-gather)
+//   PH_C   unpack of the all-gathered slabs into the resident layouts
+enum { PH_ALL = 0, PH_A = 1, PH_B = 2, PH_C = 3 };
+static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
+                           int nslabs, bool speculative, int phase);
+
 // speculative (W half-step only): the result goes to the alternate W buffers and the alternate sweep counter and is
 // NOT made current; the caller accepts it later with swap_w() / sw_active ^= 1, or simply drops it.
 static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
-                     bool partial_only = false, bool speculative = false)
+                     bool partial_only = false, bool speculative = false, int phase = PH_ALL)
 {
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
     HIPCHK(h, hipSetDevice(h->device));
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
-    if (h->any_missing && h->nranks > 1) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
+    if (h->any_missing && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
+    if (partial_only) phase = PH_A;
+    if (phase == PH_B || phase == PH_C) {
+        const HalfPlan pp = plan_half(h, which, h->rank, h->nranks);
+        return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, pp.S, speculative, phase);
+    }
     if (h->any_missing && !h->Gcols) { // NA path workspaces, on first use
         const int big = h->npad > h->mpad ? h->npad : h->mpad;
         HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
@@ -830,26 +856,62 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     }
     HIPCHK(h, hipEventRecord(h->ev_gram, h->stream_g));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gram, 0));
-    // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer and sum it over ranks: ONE all-reduce
-    const bool sharded = h->nranks > 1;
-    if (sharded) {
+    // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer; ONE all-reduce sums it over ranks
+    if (h->sharded) {
         const int ld = (which == 1) ? h->mpad : h->npad;
         const size_t cnt = (size_t)h->KP * ld;
         slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, p.S, cnt, h->red + (size_t)h->KP * h->KP);
+        if (phase == PH_A) return NNLM_OK; // test hooks: the caller performs the exchange
         if (h->comm) {
             ncclResult_t r = g_rccl.AllReduce(h->red, h->red, (size_t)h->KP * h->KP + cnt, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
             if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
         }
-        if (partial_only) return NNLM_OK;
     }
-    // 3. per-column solve
-    {
+    return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase);
+}
+
+// Columns of the factor being solved that this rank sweeps (multi-GPU): equal slabs of cpr columns (multiple of 64).
+struct ShardCols {
+    int cpr, col0, col1;
+};
+static ShardCols shard_cols(const nnlm_handle *h, int ncols)
+{
+    ShardCols c;
+    c.cpr = round_up_i((ncols + h->nranks - 1) / h->nranks, 64);
+    c.col0 = h->rank * c.cpr < ncols ? h->rank * c.cpr : ncols;
+    c.col1 = c.col0 + c.cpr < ncols ? c.col0 + c.cpr : ncols;
+    return c;
+}
+
+static int shard_unpack(nnlm_handle *h, int which)
+{
+    const int ncols = (which == 1) ? h->m : h->n;
+    const ShardCols sc = shard_cols(h, ncols);
+    const size_t tot = (size_t)h->nranks * h->KP * sc.cpr;
+    const int f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
+    if (which == 1)
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->KP, sc.cpr, h->k, ncols, h->H64,
+                                                                                   h->mpad, h->Hop, 2, h->KP, f64);
+    else
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->KP, sc.cpr, h->k, ncols,
+                                                                                   h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
+                                                                                   f64 ? 0 : 1, h->npad, f64);
+    HIPCHK(h, hipGetLastError());
+    return NNLM_OK;
+}
+
+// 3. per-column solve (+ multi-GPU: all-gather of the solved column slabs and unpack into the resident layouts)
+static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
+                           int nslabs, bool speculative, int phase)
+{
+    const int ncols = (which == 1) ? h->m : h->n;
+    if (phase != PH_C) {
         ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
         SweepArgs a;
         a.Graw = h->Graw;
         a.KPg = h->KP;
-        a.Cx = sharded ? h->red + (size_t)h->KP * h->KP : h->Cx;
-        a.nslabs = sharded ? 1 : p.S;
+        a.Cx = h->sharded ? h->red + (size_t)h->KP * h->KP : h->Cx;
+        a.nslabs = h->sharded ? 1 : nslabs;
         a.k = h->k;
         a.r0 = reg[0];
         a.r1 = reg[1];
@@ -857,10 +919,12 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         a.max_iter = inner_max_iter;
         a.rel_tol = inner_rel_tol;
         a.sweeps = h->sweeps + (speculative ? (h->sw_active ^ 1) : h->sw_active);
+        a.col0 = 0;
+        a.ocol0 = 0;
         if (which == 1) {
             a.X = h->H64;
             a.Xout = h->H64;
-            a.ldx = h->mpad;
+            a.ldx = a.ldo = h->mpad;
             a.ldc = h->mpad;
             a.slab_stride = (size_t)h->KP * h->mpad;
             a.ncols = h->m;
@@ -871,7 +935,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         } else {
             a.X = h->W64;
             a.Xout = h->W64b[h->wcur ^ 1];
-            a.ldx = h->npad;
+            a.ldx = a.ldo = h->npad;
             a.ldc = h->npad;
             a.slab_stride = (size_t)h->KP * h->npad;
             a.ncols = h->n;
@@ -881,6 +945,26 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             a.op_ld = h->npad;
         }
         a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
+        if (h->sharded) { // sweep only this rank's columns into the packed slab; the unpack writes masters and operands
+            const ShardCols sc = shard_cols(h, ncols);
+            const size_t need = (size_t)h->KP * sc.cpr;
+            if (h->pack_elems < need * h->nranks) {
+                hipFree(h->pack_send);
+                hipFree(h->pack_all);
+                h->pack_send = h->pack_all = nullptr;
+                HIPCHK(h, hipMalloc(&h->pack_send, need * 8));
+                HIPCHK(h, hipMalloc(&h->pack_all, need * h->nranks * 8));
+                h->pack_elems = need * h->nranks;
+            }
+            HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+            a.col0 = sc.col0;
+            a.ncols = sc.col1;
+            a.Xout = h->pack_send;
+            a.ldo = sc.cpr;
+            a.ocol0 = sc.col0;
+            a.op = nullptr;
+            a.op_mode = 0;
+        }
         if (h->any_missing) {
             // per-column Gram over the finite rows of each column (src/update_with_missing.cpp:90), then the solver
             const int p_len = (which == 1) ? h->n : h->m;
@@ -890,10 +974,21 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             launch_na_gram(h, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, a.ncols);
             a.Graw = h->Gcols;
             launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
-        } else
+        } else if (a.ncols > a.col0)
             launch_sweep(h, method, a);
+        HIPCHK(h, hipGetLastError());
+        if (h->sharded && phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
     }
-    HIPCHK(h, hipGetLastError());
+    if (h->sharded) {
+        const ShardCols sc = shard_cols(h, ncols);
+        if (h->comm) {
+            ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->KP * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream);
+            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        } else if (phase == PH_ALL)
+            return fail(h, NNLM_ERR_COMM, "virtual rank %d of %d has no communicator: drive it with nnlm_debug_phase()", h->rank, h->nranks);
+        int rc = shard_unpack(h, which);
+        if (rc != NNLM_OK) return rc;
+    }
     if (which == 0 && !speculative) swap_w(h);
     return NNLM_OK;
 }
@@ -917,7 +1012,7 @@ extern "C" int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, doub
     int rc = half_step(h, which, z, 0, 0.0, 1, true);
     if (rc != NNLM_OK) return rc;
     const int ld = (which == 1) ? h->mpad : h->npad;
-    if (h->nranks == 1) {
+    if (!h->sharded) {
         const HalfPlan q = plan_half(h, which, 0, 1);
         const size_t cnt = (size_t)h->KP * ld;
         slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, q.S, cnt, h->red + (size_t)h->KP * h->KP);
@@ -933,6 +1028,47 @@ extern "C" int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, doub
     if (C_out)
         for (int c = 0; c < cols; c++)
             for (int q2 = 0; q2 < k; q2++) C_out[(size_t)c * k + q2] = buf[(size_t)KP * KP + (size_t)q2 * ld + c];
+    return NNLM_OK;
+}
+
+// Test hooks for virtual ranks (several handles in one process, no communicator): run ONE phase of a sharded half-step
+// (1 = PH_A, 2 = PH_B, 3 = PH_C) and let nnlm_debug_exchange() stand in for the collective between phases.
+extern "C" int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const double reg[3], unsigned inner_max_iter, double inner_rel_tol,
+                                int method)
+{
+    if (!h || !reg || (which != 0 && which != 1) || phase < PH_A || phase > PH_C) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: bad arguments");
+    if (!h->sharded) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: handle is not sharded (call nnlm_comm_init first)");
+    return half_step(h, which, reg, inner_max_iter, inner_rel_tol, method, false, false, phase);
+}
+
+// stage 1: what ncclAllReduce does to the [G | C] buffers (host sum in rank order); stage 2: what ncclAllGather does to the
+// packed column slabs.  hs[r] must be the handle of virtual rank r; all handles describe the same problem.
+extern "C" int nnlm_debug_exchange(nnlm_handle **hs, int P, int which, int stage)
+{
+    if (!hs || P < 1 || (which != 0 && which != 1) || (stage != 1 && stage != 2)) return fail(nullptr, NNLM_ERR_ARG, "nnlm_debug_exchange: bad arguments");
+    nnlm_handle *h0 = hs[0];
+    for (int r = 0; r < P; r++) {
+        if (!hs[r] || hs[r]->nranks != P || hs[r]->rank != r) return fail(h0, NNLM_ERR_ARG, "nnlm_debug_exchange: hs[%d] is not virtual rank %d of %d", r, r, P);
+        HIPCHK(hs[r], hipSetDevice(hs[r]->device));
+        sync_all(hs[r]);
+    }
+    if (stage == 1) {
+        const int ld = (which == 1) ? h0->mpad : h0->npad;
+        const size_t cnt = (size_t)h0->KP * h0->KP + (size_t)h0->KP * ld;
+        std::vector<double> sum(cnt, 0.0), tmp(cnt);
+        for (int r = 0; r < P; r++) {
+            HIPCHK(hs[r], hipMemcpy(tmp.data(), hs[r]->red, cnt * 8, hipMemcpyDeviceToHost));
+            for (size_t e = 0; e < cnt; e++) sum[e] += tmp[e];
+        }
+        for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(hs[r]->red, sum.data(), cnt * 8, hipMemcpyHostToDevice));
+    } else {
+        const int ncols = (which == 1) ? h0->m : h0->n;
+        const ShardCols sc = shard_cols(h0, ncols);
+        const size_t per = (size_t)h0->KP * sc.cpr;
+        std::vector<double> all(per * P);
+        for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(all.data() + per * r, hs[r]->pack_send, per * 8, hipMemcpyDeviceToHost));
+        for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(hs[r]->pack_all, all.data(), per * P * 8, hipMemcpyHostToDevice));
+    }
     return NNLM_OK;
 }
 
@@ -953,7 +1089,14 @@ extern "C" int nnlm_take_sweeps(nnlm_handle *h, long long *sweeps, int reset)
     if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_take_sweeps: handle is NULL");
     HIPCHK(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    HIPCHK(h, hipMemcpyAsync(&v, h->sweeps + h->sw_active, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    const unsigned long long *src = h->sweeps + h->sw_active;
+    if (h->sharded && h->comm) {
+        HIPCHK(h, hipMemcpyAsync(h->sweeps_tmp, src, sizeof v, hipMemcpyDeviceToDevice, h->stream));
+        ncclResult_t r = g_rccl.AllReduce(h->sweeps_tmp, h->sweeps_tmp, 1, ncclUint64, ncclSum, (ncclComm_t)h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (sweep counter) failed");
+        src = h->sweeps_tmp;
+    }
+    HIPCHK(h, hipMemcpyAsync(&v, src, sizeof v, hipMemcpyDeviceToHost, h->stream));
     if (reset) HIPCHK(h, hipMemsetAsync(h->sweeps + h->sw_active, 0, sizeof v, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (sweeps) *sweeps = (long long)v;
@@ -981,21 +1124,32 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps)
         ProfScope ps(h, P_ERRORS, st);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
         size_t nb;
-        if (h->prec == NNLM_PREC_F64) {
-            dim3 grid(h->npad / ERR_TILE, h->mpad / ERR_TILE);
+        // multi-GPU: each rank reduces its share of the j-tiles; the two sums are all-reduced below
+        const int tile = (h->prec == NNLM_PREC_F64) ? ERR_TILE : ERRF_TILE;
+        const int tj = h->mpad / tile, per = (tj + h->nranks - 1) / h->nranks;
+        const int jt0 = h->sharded ? (h->rank * per < tj ? h->rank * per : tj) : 0;
+        const int jcnt = h->sharded ? ((jt0 + per < tj ? jt0 + per : tj) - jt0) : tj;
+        if (jcnt <= 0) {
+            nb = 0;
+        } else if (h->prec == NNLM_PREC_F64) {
+            dim3 grid(h->npad / ERR_TILE, jcnt);
             nb = (size_t)grid.x * grid.y;
-            errors_kernel<double><<<grid, 256, 0, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials);
+            errors_kernel<double><<<grid, 256, 0, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials, jt0);
         } else {
-            dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
+            dim3 grid(h->npad / ERRF_TILE, jcnt);
             nb = (size_t)grid.x * grid.y;
             const int k2 = round_up_i(h->k, 2);
             const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
             hipFuncSetAttribute((const void *)errors_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             const size_t cnt = (size_t)h->KP * h->mpad;
             factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(h->H64, cnt, h->Hkq);
-            errors_f32_kernel<<<grid, 256, lds, st>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials);
+            errors_f32_kernel<<<grid, 256, lds, st>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials, jt0);
         }
         reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, nb, 2, h->scal);
+        if (h->sharded && h->comm) {
+            ncclResult_t r = g_rccl.AllReduce(h->scal, h->scal, 2, ncclDouble, ncclSum, (ncclComm_t)h->comm, st);
+            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (error sums) failed");
+        }
     }
     const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
     penalty_kernel<<<nbw, 256, 0, st>>>(h->W64, h->npad, h->n, h->k, h->partials);
@@ -1004,7 +1158,14 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps)
     reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
     HIPCHK(h, hipMemcpyAsync(h->host_res, h->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (with_sweeps) {
-        HIPCHK(h, hipMemcpyAsync(h->host_res + 8, h->sweeps + h->sw_active, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        const unsigned long long *src = h->sweeps + h->sw_active;
+        if (h->sharded && h->comm) { // every rank swept its own columns: sum the integer counters
+            HIPCHK(h, hipMemcpyAsync(h->sweeps_tmp, src, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            ncclResult_t r = g_rccl.AllReduce(h->sweeps_tmp, h->sweeps_tmp, 1, ncclUint64, ncclSum, (ncclComm_t)h->comm, st);
+            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (sweep counter) failed");
+            src = h->sweeps_tmp;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->host_res + 8, src, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipMemsetAsync(h->sweeps + h->sw_active, 0, sizeof(unsigned long long), st));
     }
     HIPCHK(h, hipEventRecord(h->ev_err, st));
@@ -1098,7 +1259,8 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     }
     h->rank = rank;
     h->nranks = nranks;
-    if (!id || nranks == 1) return NNLM_OK;
+    h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
+    if (!id) return NNLM_OK;
     int rc = rccl_load();
     if (rc != NNLM_OK) return rc;
     ncclUniqueId u;
@@ -1259,7 +1421,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         if (i % trace == 0) {                                                   // src/nnmf.cpp:135-160
             HIPCHK(h, hipEventRecord(h->ev_hdone, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_hdone, 0));
-            if (i + 1 < max_iter && h->nranks == 1 && method < 3) {
+            if (i + 1 < max_iter && !h->sharded && method < 3) {
                 // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below); the error
                 // block (one more pass over A) is held back until that half-step's own pass over A is done, so the
                 // two HBM streams do not collide and the error block overlaps the compute-bound sweep instead

@@ -314,3 +314,88 @@ def test_virtual_rank_partials_sum_to_the_unsharded_buffer(pname, prec, tol, wor
             Gs += G
             Cs += Cp
         assert relF(Gs, Gf) < 1e-13 and relF(Cs, Cf) < max(tol * 1e-2, 1e-13)
+
+
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
+    """The multi-GPU code path end to end on one GPU: a real RCCL communicator of size 1 makes the handle fold its slabs,
+    call ncclAllReduce, sweep its column slab into the packed buffer, call ncclAllGather and unpack.  With one rank every
+    collective is the identity, so the result must be bit-identical to the plain path (same reduction orders)."""
+    rng = np.random.default_rng(77)
+    n, m, k = 300, 200, 9
+    A = rng.random((n, m))
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    Hm = rng.random((k, m)) < 0.1
+    reg = [0.02, 0.01, 0.03]
+    out = []
+    for sharded in (False, True):
+        with nnlm_amd.Handle(0, prec) as h:
+            if sharded:
+                h.comm_init(_lib.comm_unique_id(), 0, 1)
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0, None, Hm)
+            h.iterate(2, reg, reg, 6, 1e-9, 1)
+            h.iterate(1, reg, reg, 3, 1e-9, 2)
+            sweeps = h.take_sweeps()
+            mse, kl, pen = h.errors()
+            r = h.run(reg, reg, 5, -1.0, 0, False, 4, 1e-9, 1, 2)
+            W, H = h.get_factors()
+            out.append((W, H, sweeps, mse, kl, pen, r))
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
+    for key in ("mse_error", "mkl_error", "target_error", "average_epoch"):
+        assert np.array_equal(a[6][key], b[6][key]), key
+    assert np.array_equal(b[1][Hm], H0[Hm])
+
+
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("method", [1, 2])
+def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, method):
+    """Shard arithmetic of the multi-GPU path with `world` virtual ranks on one device: every rank contracts its slab
+    (phase 1), the host stand-in for ncclAllReduce sums the [Gram | cross-product] buffers, every rank sweeps ITS columns
+    (phase 2), the stand-in for ncclAllGather distributes the packed slabs, every rank unpacks (phase 3).  All ranks must
+    end with identical factors, equal to the single-rank result up to the all-reduce's summation order."""
+    rng = np.random.default_rng(world + method)
+    n, m, k = 500, 333, 13
+    A = rng.random((n, m))
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    Wm = rng.random((n, k)) < 0.05
+    reg = [0.02, 0.01, 0.03]
+    with nnlm_amd.Handle(0, prec) as h1:
+        h1.set_matrix(A)
+        h1.set_factors(k, W0, H0, Wm, None)
+        h1.iterate(2, reg, reg, 5, 1e-9, method)
+        W_ref, H_ref = h1.get_factors()
+        sw_ref = h1.take_sweeps()
+        mse_ref = h1.errors()[0]
+    hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
+    try:
+        for rk, h in enumerate(hs):
+            h.comm_init(None, rk, world)
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0, Wm, None)
+        for _ in range(2):
+            for which in (0, 1):
+                for h in hs:
+                    h.debug_phase(which, 1, reg, 5, 1e-9, method)
+                _lib.debug_exchange(hs, which, 1)
+                for h in hs:
+                    h.debug_phase(which, 2, reg, 5, 1e-9, method)
+                _lib.debug_exchange(hs, which, 2)
+                for h in hs:
+                    h.debug_phase(which, 3, reg, 5, 1e-9, method)
+        res = [h.get_factors() for h in hs]
+        sweeps = sum(h.take_sweeps() for h in hs)  # each rank counted its own columns
+        mse = sum(h.errors()[0] for h in hs)       # each rank reduced its share of A
+    finally:
+        for h in hs:
+            h.close()
+    for W, H in res[1:]:
+        assert np.array_equal(W, res[0][0]) and np.array_equal(H, res[0][1])
+    t = 1e-11 if pname == "f64" else tol
+    assert relF(res[0][0], W_ref) < t and relF(res[0][1], H_ref) < t
+    assert np.array_equal(res[0][0][Wm], W0[Wm])
+    assert sweeps == sw_ref
+    assert abs(mse - mse_ref) < 1e-9 * mse_ref if pname == "f64" else abs(mse - mse_ref) < 1e-5 * mse_ref
