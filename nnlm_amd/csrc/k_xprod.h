@@ -72,7 +72,18 @@ __device__ static inline int strided_count(int wave, int cnt) { return (wave < c
 // ------------------------------------------------------------------------------------------------
 // EXP: ablation switches for scripts/exp/xprod_exp.hip only (0 in the product): bit0 load the factor image only for the
 // first two stages, bit1 skip the MFMA phase, bit2 load the A image only for the first two stages.
-template <typename T, int NKQ, int EXP = 0>
+typedef float xp_f32x2 __attribute__((ext_vector_type(2)));
+typedef double xp_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct XpVec2;
+template <> struct XpVec2<float> { using type = xp_f32x2; };  // one v_pk_fma_f32 per pair
+template <> struct XpVec2<double> { using type = xp_f64x2; };
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// KT > 0: the rank is 16*NKQ + (1..KT) -- the last KT (2 or 4) rows of the factor are NOT padded to a fourth 16-wide MFMA tile
+// (k = 50 would issue 64/50 = 28 % more MFMAs); their dot products run as KT*EPV plain FMAs per fragment in the shadow of
+// the MFMAs, on the A fragment the lane already holds, and are summed across the four lane groups in the epilogue.
+template <typename T, int NKQ, int KT = 0, int EXP = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__restrict__ A, int lda,
                                                                  const T *__restrict__ Yop, int ldy,
                                                                  double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     constexpr int EPV = M::EPV;
-    constexpr int KP = 16 * NKQ;
+    constexpr int KP = 16 * (NKQ + (KT > 0 ? 1 : 0)); // rows of the factor image (= the handle's KP)
     constexpr int CE = XPROD_ROWB / (int)sizeof(T); // contraction elements per stage
     constexpr int BUF = XPROD_A_IMG_BYTES + KP * XPROD_ROWB;
     constexpr int FL = XPROD_FLUSH_ELEMS / CE;
@@ -100,6 +111,14 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     for (int b = 0; b < NKQ; b++) {
         acc[b] = acc_t{0, 0, 0, 0};
         acc64[b] = f64x4{0, 0, 0, 0};
+    }
+    using v2_t = typename XpVec2<T>::type;
+    v2_t tacc[KT > 0 ? KT : 1]; // even / odd contraction elements
+    double tacc64[KT > 0 ? KT : 1];
+#pragma unroll
+    for (int u = 0; u < (KT > 0 ? KT : 1); u++) {
+        tacc[u] = v2_t{0, 0};
+        tacc64[u] = 0.0;
     }
 
     auto issue = [&](int st, unsigned char *buf) {
@@ -130,14 +149,24 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
         // stage `st` has landed once at most the newer stage's loads are outstanding; the barrier then also tells
         // every wave that stage st-1 has been consumed, so its buffer may be refilled with stage st+2
-        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
-        __builtin_amdgcn_s_barrier();
-        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        if constexpr ((EXP & 16) == 0) {
+            wait_vmcnt((st + 1 < st1) ? per_stage : 0);
+            __builtin_amdgcn_s_barrier();
+            if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        }
         if (EXP & 2) continue;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int phys = ((lg + 4 * kk) ^ l15) * 16;
             T a[EPV], b[NKQ][EPV];
+            if constexpr ((EXP & 8) != 0) { // EXP: fragments from registers, no LDS reads
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    a[e] = (T)(lane + e + kk);
+#pragma unroll
+                    for (int nt = 0; nt < NKQ; nt++) b[nt][e] = (T)(lane - e + nt);
+                }
+            } else {
             {
                 const int row = 16 * wave + l15;
                 const f32x4 raw = *(const f32x4 *)(buf + row * XPROD_ROWB + phys);
@@ -149,10 +178,26 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
                 const f32x4 raw = *(const f32x4 *)(buf + XPROD_A_IMG_BYTES + row * XPROD_ROWB + phys);
                 __builtin_memcpy(b[nt], &raw, 16);
             }
+            }
+            T w[KT > 0 ? KT : 1][EPV];
+            if constexpr (KT > 0) { // tail rows 16*NKQ + u: same 16-byte slot of the image row, uniform over the 16 lanes of a group
+#pragma unroll
+                for (int u = 0; u < KT; u++) {
+                    const f32x4 raw = *(const f32x4 *)(buf + XPROD_A_IMG_BYTES + (16 * NKQ + u) * XPROD_ROWB + (((lg + 4 * kk) ^ u) * 16));
+                    __builtin_memcpy(w[u], &raw, 16);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < EPV; e++)
 #pragma unroll
                 for (int nt = 0; nt < NKQ; nt++) acc[nt] = M::mma(a[e], b[nt][e], acc[nt]);
+            if constexpr (KT > 0) {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 2)
+#pragma unroll
+                    for (int u = 0; u < KT; u++)
+                        tacc[u] = __builtin_elementwise_fma(v2_t{a[e], a[e + 1]}, v2_t{w[u][e], w[u][e + 1]}, tacc[u]);
+            }
         }
         if constexpr (sizeof(T) == 4) {
             if (++since_flush == FL) {
@@ -162,6 +207,13 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
 #pragma unroll
                     for (int r = 0; r < 4; r++) acc64[b][r] += (double)acc[b][r];
                     acc[b] = acc_t{0, 0, 0, 0};
+                }
+                if constexpr (KT > 0) {
+#pragma unroll
+                    for (int u = 0; u < KT; u++) {
+                        tacc64[u] += (double)tacc[u][0] + (double)tacc[u][1];
+                        tacc[u] = v2_t{0, 0};
+                    }
                 }
             }
         }
@@ -179,6 +231,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
             else v = acc[nt][r];
             out[(size_t)kq * ldc + j] = v;
         }
+    if constexpr (KT > 0) { // lane (l15, lg) holds the partial of row j = 16*wave + l15 over its quarter of the contraction
+#pragma unroll
+        for (int u = 0; u < KT; u++) {
+            double v = tacc64[u] + ((double)tacc[u][0] + (double)tacc[u][1]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) out[(size_t)(16 * NKQ + u) * ldc + j0 + 16 * wave + l15] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,7 +253,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
 // (one per M-tile e); lane (l&15) of a factor fragment holds NKQ consecutive kq (one per N-tile t):
 // the MFMA row/column <-> (i, kq) map is a permutation that is undone in the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NKQ>
+template <typename T, int NKQ, int KT = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__restrict__ A, int lda,
                                                                  const T *__restrict__ Yop,
                                                                  double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -202,7 +263,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
     using acc_t = typename M::acc_t;
     constexpr int EPV = M::EPV;
     constexpr int MT = EPV / 2;                       // M-tiles per wave (8-byte A fragment)
-    constexpr int KP = 16 * NKQ;
+    constexpr int KP = 16 * (NKQ + (KT > 0 ? 1 : 0));  // entries of a factor row (= the handle's KP)
     constexpr int BI = 64 * EPV;
     constexpr int YROW = KP * (int)sizeof(T);          // bytes of one factor row
     constexpr int YIMG = XPROD_NT_ROWS * YROW;         // bytes of the factor image (multiple of 1 KiB)
@@ -225,6 +286,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
         for (int b = 0; b < NKQ; b++) {
             acc[a][b] = acc_t{0, 0, 0, 0};
             acc64[a][b] = f64x4{0, 0, 0, 0};
+        }
+    T tacc[MT][KT > 0 ? KT : 1];
+    double tacc64[MT][KT > 0 ? KT : 1];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int u = 0; u < (KT > 0 ? KT : 1); u++) {
+            tacc[a][u] = (T)0;
+            tacc64[a][u] = 0.0;
         }
 
     auto issue = [&](int st, unsigned char *buf) {
@@ -277,6 +347,22 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             for (int e = 0; e < MT; e++)
 #pragma unroll
                 for (int t = 0; t < NKQ; t++) acc[e][t] = M::mma(a[e], b[t], acc[e][t]);
+            if constexpr (KT > 0) { // tail entries 16*NKQ + u of the factor row: the same address for all 16 lanes of a group
+                const T *hp = (const T *)(buf + XPROD_A_IMG_BYTES + row * YROW) + 16 * NKQ;
+#pragma unroll
+                for (int u = 0; u < KT; u++) {
+                    const T hv = hp[u];
+                    if constexpr (MT == 2) {
+                        using v2_t = typename XpVec2<T>::type;
+                        const v2_t t = __builtin_elementwise_fma(v2_t{a[0], a[1]}, v2_t{hv, hv}, v2_t{tacc[0][u], tacc[1][u]});
+                        tacc[0][u] = t[0];
+                        tacc[1][u] = t[1];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < MT; e++) tacc[e][u] = fma_t(a[e], hv, tacc[e][u]);
+                    }
+                }
+            }
         }
         if constexpr (sizeof(T) == 4) {
             if (++since_flush == FL) {
@@ -289,6 +375,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
                         for (int r = 0; r < 4; r++) acc64[a][b][r] += (double)acc[a][b][r];
                         acc[a][b] = acc_t{0, 0, 0, 0};
                     }
+                if constexpr (KT > 0) {
+#pragma unroll
+                    for (int a = 0; a < MT; a++)
+#pragma unroll
+                        for (int u = 0; u < KT; u++) {
+                            tacc64[a][u] += (double)tacc[a][u];
+                            tacc[a][u] = (T)0;
+                        }
+                }
             }
         }
     }
@@ -311,4 +406,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__rest
             if constexpr (MT == 2) *(f64x2 *)dst = f64x2{vv[0], vv[1]};
             else dst[0] = vv[0];
         }
+    if constexpr (KT > 0) { // lane (l15, lg): rows i = i0 + wave*16*MT + MT*l15 + e, partial over contraction rows = lg mod 4
+#pragma unroll
+        for (int u = 0; u < KT; u++)
+#pragma unroll
+            for (int e = 0; e < MT; e++) {
+                double v = tacc64[e][u] + (double)tacc[e][u];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lg == 0) out[(size_t)(16 * NKQ + u) * ldc + i0 + wave * 16 * MT + MT * l15 + e] = v;
+            }
+    }
 }

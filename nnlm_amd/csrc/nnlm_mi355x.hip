@@ -508,6 +508,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         const size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
         h->Cx_elems = eh > ew ? eh : ew;
         HIPCHK(h, hipMalloc(&h->Cx, h->Cx_elems * 8));
+        HIPCHK(h, hipMemset(h->Cx, 0, h->Cx_elems * 8)); // rows >= k of a slab are never written: keep them finite
         const int gb = (h->npad > h->mpad ? h->npad : h->mpad) / GRAM_COLS_PER_BLOCK + 1;
         HIPCHK(h, hipMalloc(&h->gslabs, (size_t)gb * h->KP * h->KP * 8));
         HIPCHK(h, hipMalloc(&h->red, ((size_t)h->KP * h->KP + (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad)) * 8));
@@ -579,33 +580,52 @@ extern "C" int nnlm_get_factors(nnlm_handle *h, double *W, double *H)
 // ---------------------------------------------------------------------------------------------
 // half-step
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NKQ>
+template <typename T, int NKQ, int KT>
 static void launch_xprod(nnlm_handle *h, int which, const HalfPlan &p)
 {
-    const int KP = 16 * NKQ;
+    const int KP = 16 * (NKQ + (KT > 0 ? 1 : 0)); // = h->KP
     if (which == 1) {
         dim3 grid(p.tiles_x, p.S);
         const int lds = xprod_tn_lds_bytes(KP);
-        hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        xprod_tn_kernel<T, NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Wop, h->npad, h->Cx, h->mpad,
-                                                                          (size_t)KP * h->mpad, p.stage_begin, p.stage_end, p.sps);
+        hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Wop, h->npad, h->Cx, h->mpad,
+                                                                              (size_t)KP * h->mpad, p.stage_begin, p.stage_end, p.sps);
     } else {
         dim3 grid(p.tiles_x, p.S);
         const int lds = xprod_nt_lds_bytes<T>(KP);
-        hipFuncSetAttribute((const void *)xprod_nt_kernel<T, NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        xprod_nt_kernel<T, NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Hop, h->Cx, h->npad,
-                                                                          (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
+        hipFuncSetAttribute((const void *)xprod_nt_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        xprod_nt_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Hop, h->Cx, h->npad,
+                                                                              (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
     }
 }
 
+// MFMA tiles / VALU tail rows for rank k: k = 16*NKQ + rem; a remainder of 1..4 rows (with at least one full tile) is
+// not padded to a whole 16-wide MFMA tile but handled as 2 or 4 tail rows (k_xprod.h).  NNLM_XPROD_TAIL=0 disables it.
 template <typename T>
 static void launch_xprod_nkq(nnlm_handle *h, int which, const HalfPlan &p)
 {
+    static int tail_ok = -1;
+    if (tail_ok < 0) {
+        const char *e = getenv("NNLM_XPROD_TAIL");
+        tail_ok = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const int full = h->k / 16, rem = h->k % 16;
+    if (tail_ok && full >= 1 && rem >= 1 && rem <= 4) {
+        const int kt = rem <= 2 ? 2 : 4;
+        switch (full * 10 + kt) {
+        case 12: launch_xprod<T, 1, 2>(h, which, p); return;
+        case 14: launch_xprod<T, 1, 4>(h, which, p); return;
+        case 22: launch_xprod<T, 2, 2>(h, which, p); return;
+        case 24: launch_xprod<T, 2, 4>(h, which, p); return;
+        case 32: launch_xprod<T, 3, 2>(h, which, p); return;
+        default: launch_xprod<T, 3, 4>(h, which, p); return;
+        }
+    }
     switch (h->NKQ) {
-    case 1: launch_xprod<T, 1>(h, which, p); break;
-    case 2: launch_xprod<T, 2>(h, which, p); break;
-    case 3: launch_xprod<T, 3>(h, which, p); break;
-    default: launch_xprod<T, 4>(h, which, p); break;
+    case 1: launch_xprod<T, 1, 0>(h, which, p); break;
+    case 2: launch_xprod<T, 2, 0>(h, which, p); break;
+    case 3: launch_xprod<T, 3, 0>(h, which, p); break;
+    default: launch_xprod<T, 4, 0>(h, which, p); break;
     }
 }
 
