@@ -96,6 +96,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     constexpr int CE = XPROD_ROWB / (int)sizeof(T); // contraction elements per stage
     constexpr int BUF = XPROD_A_IMG_BYTES + KP * XPROD_ROWB;
     constexpr int FL = XPROD_FLUSH_ELEMS / CE;
+    constexpr int YI = (16 * NKQ + KT + 3) / 4;      // 4-row pieces of the factor image that are actually used
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         }
         if ((EXP & 1) && st > st0 + 1) return;
 #pragma unroll
-        for (int t = wave; t < KP / 4; t += XPROD_WAVES) {
+        for (int t = wave; t < YI; t += XPROD_WAVES) {
             const int row = 4 * t + lg;
             const int s = l15 ^ (row & 15);
             glds16(Yop + (size_t)row * ldy + i0 + s * EPV, buf + XPROD_A_IMG_BYTES + t * 1024);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     };
 
     // loads THIS wavefront issues per stage (A image: 32 instructions over 8 waves; factor image: KP/4 instructions)
-    int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, KP / 4);
+    int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
     if (EXP & 1) per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES;
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
