@@ -49,6 +49,28 @@ def run_steps(h, steps, trace, first_index=0):
     return float(r["mse_error"][-1])
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm_summary.txt,
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command; KiB per dispatch).  gfx950 correction
+    (MI355X_MICROARCH.md, HBM section): a wide streaming read is tallied at half its bytes, so reads = 2 x FETCH_SIZE.
+    bench.py cannot attach rocprofv3 to itself: (None, None) when no summary is committed."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_summary.txt")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for line in open(files[-1]):
+        if kernel in line:
+            mt = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.eE+-]+)", line)
+            if mt and mt.group(1) == "FETCH_SIZE":
+                fetch = float(mt.group(2))
+            elif mt:
+                write = float(mt.group(2))
+    if fetch is None:
+        return None, None
+    return (2.0 * fetch + (write or 0.0)) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (2 x FETCH_SIZE + WRITE_SIZE, KiB per dispatch)"
+
+
 def cpu_baseline(A, W0, H0, k, iters, trace):
     from oracle import ref
     ref.lib()
@@ -154,8 +176,10 @@ def main():
     dom_bytes = bytes_w if dom == "xprod_w" else bytes_h
     dom_ms = kern[dom]["ms_per_launch"]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    traffic, traffic_src = pmc_traffic("xprod_nt_kernel" if dom == "xprod_w" else "xprod_tn_kernel") if world == 1 else (None, None)
     roofline = dict(bound="hbm", kernel=f"{dom} (xprod_{'nt' if dom == 'xprod_w' else 'tn'}_kernel)", achieved=achieved,
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=(achieved / HBM_PEAK_GBS if achieved else None), traffic=None,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=(achieved / HBM_PEAK_GBS if achieved else None), traffic=traffic,
+                    traffic_source=traffic_src,
                     bytes_per_launch=dom_bytes, ms_per_launch=dom_ms,
                     mfma_tflops=(2.0 * n * m * k / world / (dom_ms * 1e-3) / 1e12 if dom_ms else None))
     total_k = sum(v["total_ms"] for v in kern.values()) or 1.0
