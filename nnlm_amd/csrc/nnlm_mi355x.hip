@@ -18,6 +18,7 @@
 #include "k_prep.h"
 #include "k_sweep.h"
 #include "k_sweep_mfma.h"
+#include "k_sweep_wg.h"
 #include "k_xprod.h"
 
 #include <dlfcn.h>
@@ -90,6 +91,7 @@ struct nnlm_handle {
     double *pack_send = nullptr; // [KP][cpr]: this rank's updated columns, contiguous for ncclAllGather
     double *pack_all = nullptr;  // [nranks][KP][cpr]
     size_t pack_elems = 0;
+    double *sweep_consts = nullptr;           // [16][SWEEP_WG_CONSTS] block constants of the chain wave (k_sweep_wg.h)
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
     // profiling
@@ -243,7 +245,8 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     }
     if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
@@ -310,6 +313,7 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipFree(h->sweeps);
     hipHostFree(h->host_res);
     hipFree(h->sweeps_tmp);
+    hipFree(h->sweep_consts);
     if (h->ev_factor) hipEventDestroy(h->ev_factor);
     if (h->ev_gram) hipEventDestroy(h->ev_gram);
     if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
@@ -698,8 +702,43 @@ static bool use_mfma_sweep()
     return v == 1;
 }
 
+// SCD-LS, workgroup-specialised (k_sweep_wg.h: chain wave + update waves); NNLM_SWEEP_WG=0 keeps the one-wave kernel.
+static bool use_wg_sweep()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNLM_SWEEP_WG");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
+    if (method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
+        const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+        const bool hm = a.mask != nullptr;
+        sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
+#define NNLM_WG_SWEEP(NT_)                                                                                              \
+    {                                                                                                                   \
+        const int lds = sweep_wg_lds_bytes(NT_);                                                                        \
+        if (hm) {                                                                                                       \
+            hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+            sweep_scd_wg_kernel<NT_, true><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);               \
+        } else {                                                                                                        \
+            hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            sweep_scd_wg_kernel<NT_, false><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);              \
+        }                                                                                                               \
+    }
+        switch (h->NKQ) {
+        case 1: NNLM_WG_SWEEP(1) break;
+        case 2: NNLM_WG_SWEEP(2) break;
+        case 3: NNLM_WG_SWEEP(3) break;
+        default: NNLM_WG_SWEEP(4) break;
+        }
+#undef NNLM_WG_SWEEP
+        return;
+    }
     if (method == 1 && use_mfma_sweep()) {
         const int nb = (a.ncols + 63) / 64;
         const bool hm = a.mask != nullptr;
