@@ -247,6 +247,34 @@ def test_wrapper_warning_error_and_predict(monkeypatch):
     assert Wn["coefficients"].shape == (4, 2) and np.all(Wn["coefficients"] >= 0)
 
 
+# ---- real data: the vignette's algorithm comparison on data/nsclc.rda -------------------------------
+@pytest.mark.parametrize("method,loss,max_iter,inner", [("scd", "mse", 30, None), ("lee", "mse", 30, None), ("scd", "mkl", 40, None),
+                                                         ("lee", "mkl", 40, None), ("lee", "mse", 60, 1)])
+def test_nsclc_algorithm_comparison_matches_oracle(monkeypatch, method, loss, max_iter, inner):
+    """vignettes/Fast-And-Versatile-NMF.Rmd:281-296 (k = 15, uniform init, rel.tol = -1; iteration counts cut down):
+    the five runs of the vignette on the reference's own data set, read with nnlm_amd.rda, against the oracle --
+    factors, both error traces and the epoch trace."""
+    from nnlm_amd import rda
+    A = rda.load_rda(os.path.join(GOLDEN, "nsclc.rda"))["nsclc"].matrix()
+    rng = np.random.default_rng(123)
+    k = 15
+    init = {"W": rng.random((A.shape[0], k)), "H": rng.random((k, A.shape[1]))}
+    kw = dict(method=method, loss=loss, init=init, max_iter=max_iter, rel_tol=-1, show_warning=False)
+    if inner is not None:
+        kw["inner_max_iter"] = inner
+    args, ctx = api.prepare_nnmf(A, k, **kw)
+    o = api.finish_nnmf(ref.c_nnmf(*args), ctx)
+    for prec, tol in (("f64", 1e-8), ("f32", 1e-4)):
+        monkeypatch.setenv("NNLM_PRECISION", prec)
+        r = api.nnmf(A, k, **kw)
+        assert r.n_iteration == o.n_iteration == max_iter
+        assert relF(r.W @ r.H, o.W @ o.H) < tol
+        assert np.allclose(r.mse, o.mse, rtol=10 * tol, atol=0) and np.allclose(r.mkl, o.mkl, rtol=10 * tol, atol=1e-12)
+        assert len(r.average_epochs) == len(o.average_epochs)
+        if prec == "f64":
+            assert np.array_equal(r.average_epochs, o.average_epochs)  # integer sweep counts
+
+
 # ---- BASELINE.json configs[1] at full size ----------------------------------------------------------
 def test_config2_full_size_one_iteration_vs_oracle_and_properties():
     """20000 x 10000, k = 50, MSE+SCD: one full outer iteration against the oracle (W, H within north_star's
