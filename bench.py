@@ -186,7 +186,7 @@ def main():
     shares = {kname: round(v["total_ms"] / total_k, 4) for kname, v in kern.items()}
 
     cpu = None
-    if args.cpu_iters > 0:
+    if args.cpu_iters > 0 and world == 1:  # the CPU baseline is timed on rank 0 at N=1 only
         cpu = cpu_baseline(A, W0, H0, k, args.cpu_iters, args.trace if args.trace > 0 else 999999)
 
     out = {

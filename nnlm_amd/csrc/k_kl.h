@@ -166,3 +166,192 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     }
     if (tid == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// NNLM_PREC_F32 variant.  Same sequence of coordinate updates as above; what changes is the arithmetic of the O(p) part
+// (the mode already stores A in fp32) and the amount of cached-operand traffic:
+//   * the state vector y and the data column b are fp32 registers; the quotients b/(y+eps), w/(y+eps) use
+//     v_rcp_f32 (1 ulp) instead of an fp64 division (~20 instructions at 8 issue cycles each);
+//   * rows of the fixed factor are read from its fp32 GEMM-operand copy (Yf), half the bytes of the fp64 master;
+//   * a block solves C = 2 adjacent columns, so that every row of the fixed factor fetched from L2 serves two
+//     columns (the row traffic, ncols*k*p*4/C bytes per sweep, is what bounds this kernel);
+//   * per-thread partial sums are fp32 over EPT terms, then fp64 across the block; the scalar coordinate update
+//     (:128-150 above) stays fp64.
+struct KlFastArgs {
+    KlArgs a;
+    const float *Yf; // [KP][ldyf] fp32 copy of the fixed factor, contraction index fastest
+    int ldyf;
+};
+
+template <int EPT, int METHOD, int C>
+__global__ __launch_bounds__(KL_THREADS) void kl_fast_kernel(const KlFastArgs fa)
+{
+    const KlArgs &a = fa.a;
+    constexpr int NV = (METHOD == 4) ? 2 : 3; // sums per column: {num, sumW} or {a, b, sumW}
+    __shared__ double xs[C][64];
+    __shared__ double red[2 * NV * C * 8];
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.x * C;
+    const int k = a.k, p = a.p;
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const float tiny = (float)NNLM_TINY;
+
+    unsigned long long mword[C];
+    bool live[C]; // column exists and is not fully masked
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int col = col0 + c;
+        mword[c] = (a.mask && col < a.ncols) ? a.mask[col] : 0ull;
+        live[c] = col < a.ncols && !(a.mask && ((mword[c] & kmask) == kmask));
+        if (tid < 64) xs[c][tid] = (tid < k && col < a.ncols) ? a.X[(size_t)tid * a.ldx + col] : 0.0;
+    }
+    __syncthreads();
+
+    float y[C][EPT], b[C][EPT];
+    unsigned long long vbits[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int col = (col0 + c < a.ncols) ? col0 + c : col0;
+        const float *Acol = (const float *)a.A + (size_t)col * a.a_col_stride;
+        vbits[c] = 0ull;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = e * KL_THREADS + tid;
+            bool valid = i < p && col0 + c < a.ncols;
+            if (valid && a.bits) valid = !((a.bits[(size_t)col * a.words + (i >> 5)] >> (i & 31)) & 1u);
+            b[c][e] = valid ? Acol[(size_t)i * a.a_i_stride] : 0.0f;
+            if (valid) vbits[c] |= (1ull << e);
+            y[c][e] = 0.0f;
+        }
+    }
+    double S[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) S[c] = 0.0;
+    for (int q = 0; q < k; q++) { // y = Yt^T x, S = sum(x)
+        float w[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = e * KL_THREADS + tid;
+            w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const double xq = xs[c][q];
+            S[c] += xq;
+            const float xf = (float)xq;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, xf, y[c][e]);
+        }
+    }
+
+    double rel[C];
+    unsigned tdone[C];
+    bool run[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) rel[c] = 1.0 + a.rel_tol, tdone[c] = 0, run[c] = live[c] && a.max_iter > 0 && rel[c] > a.rel_tol;
+    int par = 0;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < C; c++) any = any || run[c];
+    while (any) { // block-uniform: all state that decides it is computed redundantly by every thread
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            if (run[c]) rel[c] = 0.0;
+        for (int q = 0; q < k; q++) {
+            bool doq[C];
+            bool anyq = false;
+#pragma unroll
+            for (int c = 0; c < C; c++) doq[c] = run[c] && !((mword[c] >> q) & 1ull), anyq = anyq || doq[c];
+            if (!anyq) continue;
+            double xq[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) xq[c] = xs[c][q]; // read BEFORE the reduction's barrier: thread 0 rewrites it after
+            float w[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = e * KL_THREADS + tid;
+                w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
+            }
+            double v[NV * C];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                float s0 = 0.0f, s1 = 0.0f, sw = 0.0f;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const float we = ((vbits[c] >> e) & 1ull) ? w[e] : 0.0f;
+                    const float r = __builtin_amdgcn_rcpf(y[c][e] + tiny);
+                    if (METHOD == 4) {
+                        s0 = __builtin_fmaf(we, b[c][e] * r, s0); // Wt.row(k) * (Aj / (wh + eps)), :141
+                    } else {
+                        const float u = we * r;                   // mu, :97
+                        s0 = __builtin_fmaf(b[c][e] * u, u, s0);  // a, :98
+                        s1 = __builtin_fmaf(b[c][e], u, s1);      // b, :99
+                    }
+                    sw += we; // sumW over the same index set
+                }
+                v[NV * c] = (double)s0;
+                if (METHOD != 4) v[NV * c + 1] = (double)s1;
+                v[NV * c + NV - 1] = (double)sw;
+            }
+            kl_block_sum<NV * C>(v, red, par);
+            par ^= 1;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                if (!doq[c]) continue; // block-uniform
+                float coef = 0.0f;
+                if (METHOD == 4) {
+                    double tmp = v[NV * c] / (v[NV * c + 1] + a.r0 * xq[c] + a.r1 * (S[c] - xq[c]) + a.r2); // :142
+                    coef = (float)((tmp - 1) * xq[c]);                                                      // :143
+                    S[c] += (tmp - 1) * xq[c];                                                              // :144
+                    if (tid == 0) xs[c][q] = xq[c] * tmp;                                                   // :145
+                    tmp = 2 * fabs(tmp - 1) / (tmp + 1);
+                    if (tmp > rel[c]) rel[c] = tmp;
+                } else {
+                    double aa = v[NV * c], bb = v[NV * c + 1] - v[NV * c + 2]; // b = dot(Aj, mu) - sumW(k), :99
+                    aa += a.r0;                                                // :100
+                    bb += aa * xq[c] - a.r2 - a.r1 * (S[c] - xq[c]);           // :101
+                    double tmp = bb / (aa + NNLM_TINY);                        // :102
+                    if (tmp < 0) tmp = 0;
+                    if (tmp != xq[c]) {
+                        coef = (float)(tmp - xq[c]);
+                        const double er = 2 * fabs(xq[c] - tmp) / (tmp + xq[c] + NNLM_TINY);
+                        if (er > rel[c]) rel[c] = er;
+                        S[c] += tmp - xq[c];
+                        if (tid == 0) xs[c][q] = tmp;
+                    }
+                }
+                if (coef != 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(coef, ((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, y[c][e]); // :106, :143
+                }
+            }
+        }
+        __syncthreads(); // xs[] written by thread 0 during this sweep is read by everyone in the next
+        any = false;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if (run[c]) {
+                tdone[c]++;
+                run[c] = tdone[c] < a.max_iter && rel[c] > a.rel_tol;
+            }
+            any = any || run[c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int col = col0 + c;
+        if (col < a.ncols && tid < k) {
+            const double xv = xs[c][tid];
+            a.Xout[(size_t)tid * a.ldx + col] = xv;
+            if (a.op_mode == 1) ((float *)a.op)[(size_t)tid * a.op_ld + col] = (float)xv;
+            else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + tid] = (float)xv;
+        }
+    }
+    if (tid == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) tot += tdone[c];
+        if (tot) atomicAdd(a.sweeps, tot);
+    }
+}

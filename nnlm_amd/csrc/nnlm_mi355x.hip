@@ -784,6 +784,39 @@ static void launch_kl(int method, const KlArgs &a, hipStream_t s)
     else launch_kl_m<T, 64>(method, a, s);
 }
 
+// F32 mode: kl_fast_kernel (fp32 state, v_rcp_f32 quotients, fp32 rows of the fixed factor, two columns per block);
+// NNLM_KL_FAST=0 keeps the fp64 kernel for A/B runs.
+template <int EPT, int C>
+static void launch_kl_fast_m(int method, const KlFastArgs &fa, hipStream_t s)
+{
+    const int nb = (fa.a.ncols + C - 1) / C;
+    if (method == 3) kl_fast_kernel<EPT, 3, C><<<nb, KL_THREADS, 0, s>>>(fa);
+    else kl_fast_kernel<EPT, 4, C><<<nb, KL_THREADS, 0, s>>>(fa);
+}
+static void launch_kl_fast(int method, const KlFastArgs &fa, hipStream_t s)
+{
+    const int ept = (fa.a.p + KL_THREADS - 1) / KL_THREADS;
+    if (ept <= 1) launch_kl_fast_m<1, 2>(method, fa, s);
+    else if (ept <= 2) launch_kl_fast_m<2, 2>(method, fa, s);
+    else if (ept <= 4) launch_kl_fast_m<4, 2>(method, fa, s);
+    else if (ept <= 8) launch_kl_fast_m<8, 2>(method, fa, s);
+    else if (ept <= 16) launch_kl_fast_m<16, 2>(method, fa, s);
+    else if (ept <= 24) launch_kl_fast_m<24, 2>(method, fa, s);
+    else if (ept <= 32) launch_kl_fast_m<32, 2>(method, fa, s);
+    else if (ept <= 40) launch_kl_fast_m<40, 2>(method, fa, s);
+    else if (ept <= 48) launch_kl_fast_m<48, 1>(method, fa, s);
+    else launch_kl_fast_m<64, 1>(method, fa, s);
+}
+static bool use_kl_fast()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNLM_KL_FAST");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <int NKQ>
 static void launch_colsolve_m(int method, const SweepArgs &a, size_t g_stride, hipStream_t s)
 {
@@ -854,7 +887,20 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     {
         ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
         if (h->prec == NNLM_PREC_F64) launch_kl<double>(method, a, h->stream);
-        else launch_kl<float>(method, a, h->stream);
+        else if (use_kl_fast()) {
+            KlFastArgs fa;
+            fa.a = a;
+            if (which == 1) {
+                fa.Yf = (const float *)h->Wop; // the TN operand copy of W: [KP][npad]
+                fa.ldyf = h->npad;
+            } else {
+                const size_t cnt = (size_t)h->KP * h->mpad; // [KP][mpad] fp32 copy of H (also used by the error block)
+                factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
+                fa.Yf = h->Hkq;
+                fa.ldyf = h->mpad;
+            }
+            launch_kl_fast(method, fa, h->stream);
+        } else launch_kl<float>(method, a, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     if (which == 0 && !speculative) swap_w(h);

@@ -3,7 +3,8 @@ the committed golden fixtures.  Needs a real MI355X: run with `pytest -m gpu`.
 
 Tolerances: F64 mode (A, GEMMs and sweeps all fp64) is compared at 1e-10 relative Frobenius and its integer
 outputs (sweep counts, n_iteration, trace lengths) must be exact; F32 mode (A and cross-product GEMMs in fp32
-MFMA, everything else fp64) at 2e-5 for single half-steps and at north_star's 1e-4 for whole runs."""
+MFMA, everything else fp64; the KL solvers with fp32 state vectors) at 2e-5 for single least-squares half-steps and
+at north_star's 1e-4 for KL half-steps and whole runs."""
 import os
 import sys
 
@@ -51,6 +52,8 @@ def test_half_step_matches_oracle(pname, prec, tol, method, shape):
     W0, H0 = rng.random((n, k)), rng.random((k, m))
     reg = [0.02, 0.01, 0.03]
     inner = 5 if method < 3 else 2
+    if method >= 3 and pname == "f32":
+        tol = 1e-4  # F32 mode runs the KL solvers with fp32 state and v_rcp_f32 quotients (k_kl.h, kl_fast_kernel)
     with nnlm_amd.Handle(0, prec) as h:
         h.set_matrix(A)
         h.set_factors(k, W0, H0)
