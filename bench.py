@@ -182,6 +182,15 @@ def main():
                     traffic_source=traffic_src,
                     bytes_per_launch=dom_bytes, ms_per_launch=dom_ms,
                     mfma_tflops=(2.0 * n * m * k / world / (dom_ms * 1e-3) / 1e12 if dom_ms else None))
+    # the sweeps are a loop-carried recurrence (no HBM/MFMA roofline): reported as achieved fp64
+    # arithmetic of the recurrence itself, inner*cols*k*(2k+8) flops per launch, against the fp64 vector peak
+    sweep_info = {}
+    for kname, cols in (("sweep_h", m), ("sweep_w", n)):
+        ms_l = kern[kname]["ms_per_launch"]
+        if ms_l:
+            fl = INNER * (cols / world) * k * (2 * k + 8)
+            sweep_info[kname] = dict(flops_per_launch=fl, tflops=fl / (ms_l * 1e-3) / 1e12, frac_of_fp64_peak=fl / (ms_l * 1e-3) / 1e12 / 78.6,
+                                     note="latency bound: 2500 dependent coordinate steps per column")
     total_k = sum(v["total_ms"] for v in kern.values()) or 1.0
     shares = {kname: round(v["total_ms"] / total_k, 4) for kname, v in kern.items()}
 
@@ -212,6 +221,7 @@ def main():
         "cpu_baseline": cpu,
         "kernels": kern,
         "kernel_time_share": shares,
+        "sweeps": sweep_info,
         "profiled_ms_per_step": 1e3 * prof_elapsed / args.steps,
         "upload_and_prep_s": upload_s,
     }
