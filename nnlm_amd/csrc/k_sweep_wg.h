@@ -30,6 +30,9 @@
 #define SWEEP_WG_LCOLS 64    // rows of the LDS images (one per chain-wave lane)
 #define SWEEP_WG_CONSTS 32 // doubles per block in the constants image
 // SWEEP_WG_TIMING (scripts/exp/sweepwg_exp.hip only): cycles spent working / waiting at the step barrier, per role
+#ifndef SWEEP_WG_ABL
+#define SWEEP_WG_ABL 0 // ablation bits (scripts/exp/sweepwg_exp.hip only): 1 no constant reloads, 2 no LDS writes, 4 no near, 8 no chain
+#endif
 #ifdef SWEEP_WG_TIMING
 #define SWG_T0() const unsigned long long swg_t0 = __builtin_readcyclecounter();
 #define SWG_SYNC(work, wait)                                                                                            \
@@ -259,6 +262,10 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wg_kernel(const Sw
                 double near[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
+                    if (SWEEP_WG_ABL & 4) {
+                        near[s] = dd[s];
+                        continue;
+                    }
                     double acc = dd[0] * gn[4 * s];
                     acc = __builtin_fma(dd[1], gn[4 * s + 1], acc);
                     acc = __builtin_fma(dd[2], gn[4 * s + 2], acc);
@@ -271,6 +278,11 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wg_kernel(const Sw
                 double xn[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
+                    if (SWEEP_WG_ABL & 8) {
+                        dd[s] = act ? m[s] * 1e-30 : 0.0;
+                        xn[s] = xs[s];
+                        continue;
+                    }
                     const double q0 = m[s] * cc.rg[s];
                     const double rr = __builtin_fma(-q0, cc.gd[s], m[s]);
                     const double quo = __builtin_fma(rr, cc.rg[s], q0); // = mu / G[q][q], correctly rounded
@@ -283,10 +295,12 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wg_kernel(const Sw
 #pragma unroll
                     for (int s2 = s + 1; s2 < 4; s2++) m[s2] = __builtin_fma(dd[s], gl[s2][s], m[s2]);
                 }
-                *(f64x2 *)&dbuf[par][lane * 4] = f64x2{dd[0], dd[1]};
-                *(f64x2 *)&dbuf[par][lane * 4 + 2] = f64x2{dd[2], dd[3]};
-                *(f64x2 *)&xrow[4 * b] = f64x2{xn[0], xn[1]};
-                *(f64x2 *)&xrow[4 * b + 2] = f64x2{xn[2], xn[3]};
+                if (!(SWEEP_WG_ABL & 2)) {
+                    *(f64x2 *)&dbuf[par][lane * 4] = f64x2{dd[0], dd[1]};
+                    *(f64x2 *)&dbuf[par][lane * 4 + 2] = f64x2{dd[2], dd[3]};
+                    *(f64x2 *)&xrow[4 * b] = f64x2{xn[0], xn[1]};
+                    *(f64x2 *)&xrow[4 * b + 2] = f64x2{xn[2], xn[3]};
+                }
                 // rel-change tests (src/base_algorithms.cpp:29-32), division-free.  Only "did ANY coordinate of the sweep move
                 // by more than rel_tol" matters, so once every column of the wave has its flag the tests of the remaining
                 // blocks of this sweep are skipped (wave-uniform branch; same decisions, ~20 fp64 instructions less)
@@ -306,12 +320,12 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wg_kernel(const Sw
                     flag = (0.0 > tol) ? 1 : 0;
                 }
                 // next step's operands: constants through the scalar cache, x from this wave's own LDS rows
-                {
+                if (!(SWEEP_WG_ABL & 1)) {
                     const auto *cb = cdat + b * SWEEP_WG_CONSTS + 16;
 #pragma unroll
                     for (int i = 0; i < 16; i++) gn[i] = cb[i];
+                    load_chain(nb, cc);
                 }
-                load_chain(nb, cc);
                 x01 = *(const f64x2 *)&xrow[4 * nb];
                 x23 = *(const f64x2 *)&xrow[4 * nb + 2];
                 SWG_SYNC(swg_work, swg_wait)
