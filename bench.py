@@ -214,9 +214,13 @@ def main():
         "final_mse": final_mse,
         "config": {"workload": f"nnmf(A, k={k}) MSE+SCD on {n}x{m} dense A (BASELINE.json configs[1])", "n": n, "m": m, "k": k,
                    "inner_max_iter": INNER, "inner_rel_tol": INNER_TOL, "trace": args.trace, "rel_tol": -1,
-                   "arith": ("A + cross-product GEMMs fp32 MFMA (fp64 flush every 256), Gram/mu/sweeps fp64" if s == 4
+                   "arith": (("A fp32 (4 B/element); cross products: operands as split fp16 pairs (hi + lo*2^-11, 22 bits) on "
+                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation folded into fp64 every 256 elements"
+                              if os.environ.get("NNLM_XPROD", "") != "f32" else
+                              "A + cross-product GEMMs fp32 MFMA (fp64 flush every 256)") + "; Gram/mu/sweeps fp64" if s == 4
                              else "all fp64 (v_mfma_f64_16x16x4_f64)"),
-                   "parallelism": f"contraction-sharded x{world}, 1 RCCL all-reduce per half-step" if world > 1 else "1 GPU"},
+                   "parallelism": (f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
+                                   if world > 1 else "1 GPU")},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "kernels": kern,

@@ -1,0 +1,217 @@
+// k_xprod16.h -- the A-streaming cross product with split-fp16 operands on the fp16 matrix cores.
+//
+// Same job as xprod_tn_kernel (k_xprod.h):  C[kq, c] = sum_i Y[kq, i] * A[i, c]  for the columns c of one resident
+// matrix, contraction index i contiguous.  The fp32 kernel is bound by its MFMA phase (v_mfma_f32_16x16x4_f32 runs at
+// 1/16 of the fp16 rate) while HBM could deliver A in ~0.6 of its time.  Here every operand value v (pre-scaled by a
+// power of two so that max|v| lands in [2^14, 2^15)) is stored as TWO fp16 numbers in the SAME 4 bytes per element,
+//      hi = fp16(v),      lo = fp16((v - hi) * 2^11)            v = hi + lo * 2^-11  to 2^-22 relative
+// and the product is accumulated in fp32 by three v_mfma_f32_16x16x32_f16 per 32 contraction elements:
+//      main += hi_a * hi_y          cross += hi_a * lo_y + lo_a * hi_y          C = main + cross * 2^-11
+// (lo_a * lo_y, 2^-22 relative, is dropped).  fp32 partial sums are folded into fp64 every 256 contraction elements
+// exactly like the fp32 kernel.  HBM traffic and the LDS images have the same size as in the fp32 kernel; the MFMA
+// phase is 4x shorter, so the kernel runs at the speed the loads arrive.
+//
+// Layout ("split rows"): a row of the contraction index is cut into chunks of 64 elements; a chunk is 256 bytes =
+// [64 x hi | 64 x lo].  A16 [cols][plen/64][2][64], Y16 [KP][plen/64][2][64] (plen = padded contraction length).
+// The W half-step uses the same kernel on a transposed split copy of A (A16T), so there is no "NT" variant.
+// Scaling: A by 2^eA once per matrix, the factor by 2^eY per half-step (absmax_kernel + factor16_kernel); the epilogue
+// multiplies by 2^-(eA+eY), read from device memory.
+#pragma once
+#include "common.h"
+#include "k_xprod.h"
+
+typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
+#define XPROD16_LO_SCALE 2048.0f // 2^11
+
+// exponent e such that max * 2^e lies in [2^14, 2^15) (0 for max = 0 / non-finite)
+__host__ __device__ static inline int split16_exponent(float maxabs)
+{
+    if (!(maxabs > 0.0f) || maxabs > 3.0e38f) return 0;
+    int ex;
+    (void)frexpf(maxabs, &ex); // maxabs = f * 2^ex, f in [0.5, 1)
+    return 15 - ex;
+}
+
+__device__ static inline void split16(float v, float scale, _Float16 &hi, _Float16 &lo)
+{
+    const float x = v * scale;
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * XPROD16_LO_SCALE);
+}
+
+// scal_exp[0] = eA (written by the host), scal_exp[1] = eY (written by factor16_kernel's companion absmax pass)
+template <int NKQ, int EXP = 0>
+__global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_t *__restrict__ A16, int lda,   // lda: elements per column
+                                                                   const uint32_t *__restrict__ Y16, int ldy,   // ldy: elements per row
+                                                                   double *__restrict__ Cx, int ldc, size_t slab_stride,
+                                                                   int stage_begin, int stage_end, int stages_per_split,
+                                                                   const int *__restrict__ scal_exp)
+{
+    constexpr int KP = 16 * NKQ;
+    constexpr int BUF = XPROD_A_IMG_BYTES + KP * XPROD_ROWB;
+    constexpr int FL = XPROD_FLUSH_ELEMS / 64;
+    constexpr int YI = KP / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int j0 = blockIdx.x * XPROD_TN_BJ;
+    int st0 = stage_begin + blockIdx.y * stages_per_split;
+    int st1 = st0 + stages_per_split;
+    if (st1 > stage_end) st1 = stage_end;
+
+    f32x4 accm[NKQ], accx[NKQ];
+    f64x4 acc64[NKQ];
+#pragma unroll
+    for (int b = 0; b < NKQ; b++) {
+        accm[b] = f32x4{0, 0, 0, 0};
+        accx[b] = f32x4{0, 0, 0, 0};
+        acc64[b] = f64x4{0, 0, 0, 0};
+    }
+
+    // a stage = one 256-byte chunk ([64 hi | 64 lo]) of 128 columns of A and of KP rows of the factor; the sixteen
+    // 16-byte slots of a row are XOR-swizzled with the row index through the global source address (as in k_xprod.h)
+    auto issue = [&](int st, unsigned char *buf) {
+        const size_t c0 = (size_t)((EXP & 4) && st > st0 + 1 ? st0 : st) * 64; // element offset of the chunk (64 words of 4 bytes)
+#pragma unroll
+        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(A16 + (size_t)(j0 + row) * lda + c0 + s * 4, buf + t * 1024);
+        }
+#pragma unroll
+        for (int t = wave; t < YI; t += XPROD_WAVES) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(Y16 + (size_t)row * ldy + c0 + s * 4, buf + XPROD_A_IMG_BYTES + t * 1024);
+        }
+    };
+    const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
+    if (st0 < st1) issue(st0, smem);
+    if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
+    int since_flush = 0;
+    for (int st = st0; st < st1; ++st) {
+        unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
+        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        if (EXP & 2) continue;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks per stage; lane (l15, lg) holds elements 32*c2 + 8*lg .. +7
+            const int arow = 16 * wave + l15;
+            const int sh = (4 * c2 + lg), sl = 8 + 4 * c2 + lg; // logical 16-byte slots of the hi / lo halves
+            const xh8 ah = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sh ^ l15) * 16));
+            const xh8 al = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sl ^ l15) * 16));
+            xh8 yh[NKQ], yl[NKQ];
+#pragma unroll
+            for (int nt = 0; nt < NKQ; nt++) {
+                const unsigned char *yrow = buf + XPROD_A_IMG_BYTES + (16 * nt + l15) * XPROD_ROWB;
+                yh[nt] = *(const xh8 *)(yrow + ((sh ^ l15) * 16));
+                yl[nt] = *(const xh8 *)(yrow + ((sl ^ l15) * 16));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NKQ; nt++) {
+                accm[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh[nt], accm[nt], 0, 0, 0);
+                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl[nt], accx[nt], 0, 0, 0);
+                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh[nt], accx[nt], 0, 0, 0);
+            }
+        }
+        if (++since_flush == FL) {
+            since_flush = 0;
+#pragma unroll
+            for (int b = 0; b < NKQ; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc64[b][r] += (double)accm[b][r] + (double)accx[b][r] * (1.0 / XPROD16_LO_SCALE);
+                accm[b] = f32x4{0, 0, 0, 0};
+                accx[b] = f32x4{0, 0, 0, 0};
+            }
+        }
+    }
+    // epilogue: D[M = column, N = kq], undo the two power-of-two scalings (exact)
+    const double unscale = ldexp(1.0, -(scal_exp[0] + scal_exp[1]));
+    double *out = Cx + (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int nt = 0; nt < NKQ; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kq = 16 * nt + l15;
+            const int j = j0 + 16 * wave + 4 * lg + r;
+            const double v = acc64[nt][r] + (double)accm[nt][r] + (double)accx[nt][r] * (1.0 / XPROD16_LO_SCALE);
+            out[(size_t)kq * ldc + j] = v * unscale;
+        }
+}
+
+// ---- operand preparation -------------------------------------------------------------------------------------------
+// maxbits = max over all elements of the bit pattern of |x| as float (non-negative floats order like unsigned ints)
+__global__ __launch_bounds__(256) void absmax_f64_kernel(const double *__restrict__ X, int ld, int ncols, int k, unsigned *__restrict__ maxbits)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    float mx = 0.0f;
+    if (col < ncols)
+        for (int q = 0; q < k; q++) mx = fmaxf(mx, fabsf((float)X[(size_t)q * ld + col]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxbits, __float_as_uint(mx));
+}
+
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float *__restrict__ X, size_t count, unsigned *__restrict__ maxbits)
+{
+    float mx = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(X[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxbits, __float_as_uint(mx));
+}
+
+// Y16 [KP][plen/64][2][64] from the fp64 master X [KP][ld]; exp_out = the exponent used (read by the cross product).
+// One thread per element; maxbits comes from absmax_f64_kernel (zeroed by the host before that pass).
+__global__ __launch_bounds__(256) void factor16_kernel(const double *__restrict__ X, int ld, int ncols, int k, int KP, int plen,
+                                                       unsigned *__restrict__ maxbits, int *__restrict__ exp_out, uint32_t *__restrict__ Y16)
+{
+    const int e = split16_exponent(__uint_as_float(*maxbits));
+    const float scale = ldexpf(1.0f, e);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; // over KP * plen
+    if (idx < (size_t)KP * plen) {
+        const int q = (int)(idx / plen), i = (int)(idx % plen);
+        const float v = (q < k && i < ncols) ? (float)X[(size_t)q * ld + i] : 0.0f;
+        _Float16 hi, lo;
+        split16(v, scale, hi, lo);
+        _Float16 *row = (_Float16 *)(Y16 + (size_t)q * plen + (size_t)(i >> 6) * 64);
+        row[i & 63] = hi;
+        row[64 + (i & 63)] = lo;
+    }
+    if (idx == 0) *exp_out = e;
+}
+
+// A16 [cols][plen/64][2][64] from the resident fp32 A [cols][lda] (same column-major geometry, plen = lda)
+__global__ __launch_bounds__(256) void a16_convert_kernel(const float *__restrict__ A, size_t count, float scale, uint32_t *__restrict__ A16)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count) return;
+    _Float16 hi, lo;
+    split16(A[idx], scale, hi, lo);
+    _Float16 *row = (_Float16 *)(A16 + (idx & ~(size_t)63));
+    row[idx & 63] = hi;
+    row[64 + (idx & 63)] = lo;
+}
+
+// A16T [npad][mpad/64][2][64]: split copy of A transposed (row i of A becomes a "column"), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void a16_transpose_kernel(const float *__restrict__ A, int lda, int npad, int mpad, float scale,
+                                                            uint32_t *__restrict__ A16T)
+{
+    __shared__ float tile[64][65];
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int jj = e / 64, ii = e % 64;
+        tile[jj][ii] = A[(size_t)(j0 + jj) * lda + i0 + ii];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int ii = e / 64, jj = e % 64;
+        _Float16 hi, lo;
+        split16(tile[jj][ii], scale, hi, lo);
+        _Float16 *row = (_Float16 *)(A16T + (size_t)(i0 + ii) * mpad + (size_t)j0);
+        row[jj] = hi;
+        row[64 + jj] = lo;
+    }
+}

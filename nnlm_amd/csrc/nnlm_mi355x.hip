@@ -20,6 +20,7 @@
 #include "k_sweep_mfma.h"
 #include "k_sweep_wg.h"
 #include "k_xprod.h"
+#include "k_xprod16.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -92,6 +93,11 @@ struct nnlm_handle {
     double *pack_all = nullptr;  // [nranks][KP][cpr]
     size_t pack_elems = 0;
     double *sweep_consts = nullptr;           // [16][SWEEP_WG_CONSTS] block constants of the chain wave (k_sweep_wg.h)
+    // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
+    bool x16 = false;
+    uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
+    unsigned *maxbits = nullptr; // device: bit pattern of max|factor| (absmax_f64_kernel)
+    int *scal_exp = nullptr;     // device: {eA, eY}
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
     // profiling
@@ -118,6 +124,17 @@ static int fail(nnlm_handle *h, int code, const char *fmt, ...)
         hipError_t e__ = (call);                                                                                     \
         if (e__ != hipSuccess) return fail(h, NNLM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
+
+// split-fp16 cross products: the default of the F32 mode; NNLM_XPROD=f32 keeps the fp32 MFMA kernels
+static bool x16_enabled(int precision)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNLM_XPROD");
+        v = (e && strcmp(e, "f32") == 0) ? 0 : 1;
+    }
+    return precision == NNLM_PREC_F32 && v == 1;
+}
 
 static size_t esize(const nnlm_handle *h) { return h->prec == NNLM_PREC_F64 ? 8 : 4; }
 
@@ -246,12 +263,15 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess) {
+        hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
+        hipMalloc(&h->maxbits, sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 2 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
     hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
+    hipMemsetAsync(h->scal_exp, 0, 2 * sizeof(int), h->stream);
     hipStreamSynchronize(h->stream);
+    h->x16 = x16_enabled(precision);
     *out = h;
     return NNLM_OK;
 }
@@ -272,6 +292,8 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Wmask);
     hipFree(h->Hmask);
     hipFree(h->Cx);
+    hipFree(h->Y16);
+    h->Y16 = nullptr;
     hipFree(h->gslabs);
     hipFree(h->red);
     hipFree(h->pack_send);
@@ -291,6 +313,9 @@ static void free_factors(nnlm_handle *h)
 static void free_matrix(nnlm_handle *h)
 {
     hipFree(h->A);
+    hipFree(h->A16);
+    hipFree(h->A16T);
+    h->A16 = h->A16T = nullptr;
     hipFree(h->miss);
     hipFree(h->missT);
     hipFree(h->partials);
@@ -314,6 +339,8 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipHostFree(h->host_res);
     hipFree(h->sweeps_tmp);
     hipFree(h->sweep_consts);
+    hipFree(h->maxbits);
+    hipFree(h->scal_exp);
     if (h->ev_factor) hipEventDestroy(h->ev_factor);
     if (h->ev_gram) hipEventDestroy(h->ev_gram);
     if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
@@ -385,6 +412,26 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
     h->n_non_missing = cnt;
     h->any_missing = cnt != (double)n * (double)m;
     h->kl_const = klc / cnt; // mean((A+eps) log(A+eps) - A) over finite entries, src/nnmf.cpp:70,73
+    if (h->x16) { // split-fp16 copies of A and of its transpose, pre-scaled by 2^eA (k_xprod16.h)
+        const size_t cnt_a = (size_t)h->npad * h->mpad;
+        HIPCHK(h, hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream));
+        absmax_f32_kernel<<<1024, 256, 0, h->stream>>>((const float *)h->A, cnt_a, h->maxbits);
+        unsigned mb = 0;
+        HIPCHK(h, hipMemcpyAsync(&mb, h->maxbits, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float mx;
+        memcpy(&mx, &mb, 4);
+        const int eA = split16_exponent(mx);
+        HIPCHK(h, hipMemcpyAsync(h->scal_exp, &eA, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMalloc(&h->A16, cnt_a * 4 + 4096));
+        HIPCHK(h, hipMalloc(&h->A16T, cnt_a * 4 + 4096));
+        const float scale = ldexpf(1.0f, eA);
+        a16_convert_kernel<<<(unsigned)((cnt_a + 255) / 256), 256, 0, h->stream>>>((const float *)h->A, cnt_a, scale, h->A16);
+        dim3 gt(h->npad / 64, h->mpad / 64);
+        a16_transpose_kernel<<<gt, 256, 0, h->stream>>>((const float *)h->A, h->npad, h->npad, h->mpad, scale, h->A16T);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+    }
     if (h->any_missing) { // row-wise view of the missing mask for the W half-step
         const size_t wordsT = (size_t)h->npad * (h->mpad / 32);
         HIPCHK(h, hipMalloc(&h->missT, wordsT * 4 + 64));
@@ -446,6 +493,9 @@ static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
         const int CE = XPROD_ROWB / (int)esize(h);
         stages_total = h->npad / CE;
         tiles_x = h->mpad / XPROD_TN_BJ;
+    } else if (h->x16) { // split-fp16: the TN kernel on the transposed copy, tiles of 128 rows of A, stages of 64 columns
+        stages_total = h->mpad / 64;
+        tiles_x = h->npad / XPROD_TN_BJ;
     } else {
         stages_total = h->mpad / XPROD_NT_ROWS;
         const int BI = 64 * (16 / (int)esize(h));
@@ -509,7 +559,8 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * 8));
         // split-K slabs: sized for the worst case over ranks (nranks = 1 gives the largest S)
         const HalfPlan ph = plan_half(h, 1, 0, 1), pw = plan_half(h, 0, 0, 1);
-        const size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
+        size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
+        if (h->x16) HIPCHK(h, hipMalloc(&h->Y16, (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad) * 4 + 4096));
         h->Cx_elems = eh > ew ? eh : ew;
         HIPCHK(h, hipMalloc(&h->Cx, h->Cx_elems * 8));
         HIPCHK(h, hipMemset(h->Cx, 0, h->Cx_elems * 8)); // rows >= k of a slab are never written: keep them finite
@@ -630,6 +681,37 @@ static void launch_xprod_nkq(nnlm_handle *h, int which, const HalfPlan &p)
     case 2: launch_xprod<T, 2, 0>(h, which, p); break;
     case 3: launch_xprod<T, 3, 0>(h, which, p); break;
     default: launch_xprod<T, 4, 0>(h, which, p); break;
+    }
+}
+
+// Split-fp16 cross product (k_xprod16.h): split copy of the fixed factor scaled by its own power of two, then the
+// A-streaming kernel on A16 (H half-step) or A16T (W half-step: the transposed copy makes it the same "TN" kernel).
+template <int NKQ>
+static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int ldy, int ldc, const HalfPlan &p)
+{
+    const int KP = 16 * NKQ;
+    dim3 grid(p.tiles_x, p.S);
+    const int lds = xprod_tn_lds_bytes(KP);
+    hipFuncSetAttribute((const void *)xprod16_tn_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16, lda, h->Y16, ldy, h->Cx, ldc, (size_t)KP * ldc, p.stage_begin,
+                                                                    p.stage_end, p.sps, h->scal_exp);
+}
+static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    const double *Ym = (which == 1) ? h->W64 : h->H64;
+    const int ldm = (which == 1) ? h->npad : h->mpad;       // leading dimension of the master = padded contraction length
+    const int plen_true = (which == 1) ? h->n : h->m;
+    hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
+    absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->maxbits);
+    const size_t cnt = (size_t)h->KP * ldm;
+    factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, h->maxbits, h->scal_exp + 1, h->Y16);
+    const uint32_t *A16 = (which == 1) ? h->A16 : h->A16T;
+    const int ldc = (which == 1) ? h->mpad : h->npad;
+    switch (h->NKQ) {
+    case 1: launch_xprod16_m<1>(h, A16, ldm, ldm, ldc, p); break;
+    case 2: launch_xprod16_m<2>(h, A16, ldm, ldm, ldc, p); break;
+    case 3: launch_xprod16_m<3>(h, A16, ldm, ldm, ldc, p); break;
+    default: launch_xprod16_m<4>(h, A16, ldm, ldm, ldc, p); break;
     }
 }
 
@@ -944,6 +1026,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
         if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
+        else if (h->x16) launch_xprod16(h, which, p);
         else launch_xprod_nkq<float>(h, which, p);
     }
     if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream)); // the error block starts once A is no longer streamed
@@ -951,7 +1034,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     int gslabs = 0;
     {
         ProfScope ps(h, P_GRAM, h->stream_g);
-        const int CE = (which == 1) ? XPROD_ROWB / (int)esize(h) : XPROD_NT_ROWS;
+        const int CE = (which == 1) ? XPROD_ROWB / (int)esize(h) : (h->x16 ? 64 : XPROD_NT_ROWS);
         int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
         const int lim = (which == 1) ? h->n : h->m;
         if (c1 > lim) c1 = lim;
@@ -1394,12 +1477,13 @@ extern "C" int nnlm_shard_range(int n, int m, int precision, int which, int rank
         return fail(nullptr, NNLM_ERR_ARG, "nnlm_shard_range: bad arguments");
     nnlm_handle t;
     t.prec = precision;
+    t.x16 = x16_enabled(precision);
     t.n = n;
     t.m = m;
     t.npad = round_up_i(n, NNLM_PAD_N);
     t.mpad = round_up_i(m, NNLM_PAD_M);
     const HalfPlan p = plan_half(&t, which, rank, nranks);
-    const int CE = (which == 1) ? XPROD_ROWB / (int)esize(&t) : XPROD_NT_ROWS;
+    const int CE = (which == 1) ? XPROD_ROWB / (int)esize(&t) : (t.x16 ? 64 : XPROD_NT_ROWS);
     const int lim = (which == 1) ? n : m;
     int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
     if (c1 > lim) c1 = lim;
