@@ -176,8 +176,10 @@ def main():
     dom_bytes = bytes_w if dom == "xprod_w" else bytes_h
     dom_ms = kern[dom]["ms_per_launch"]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
-    traffic, traffic_src = pmc_traffic("xprod_nt_kernel" if dom == "xprod_w" else "xprod_tn_kernel") if world == 1 else (None, None)
-    roofline = dict(bound="hbm", kernel=f"{dom} (xprod_{'nt' if dom == 'xprod_w' else 'tn'}_kernel)", achieved=achieved,
+    x16 = s == 4 and os.environ.get("NNLM_XPROD", "") != "f32"   # split-fp16 cross products: one kernel for both half-steps
+    kname = "xprod16_tn_kernel" if x16 else ("xprod_nt_kernel" if dom == "xprod_w" else "xprod_tn_kernel")
+    traffic, traffic_src = pmc_traffic(kname) if world == 1 else (None, None)
+    roofline = dict(bound="hbm", kernel=f"{dom} ({kname})", achieved=achieved,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=(achieved / HBM_PEAK_GBS if achieved else None), traffic=traffic,
                     traffic_source=traffic_src,
                     bytes_per_launch=dom_bytes, ms_per_launch=dom_ms,

@@ -696,15 +696,22 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
     xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16, lda, h->Y16, ldy, h->Cx, ldc, (size_t)KP * ldc, p.stage_begin,
                                                                     p.stage_end, p.sps, h->scal_exp);
 }
-static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
+// split copy of the fixed factor, scaled by its own power of two (two small kernels, outside the cross product's timing
+// scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
+// made the step SLOWER by 1 % -- the Gram kernels then overlap more of the (now HBM-bound) cross product.
+static void prepare_factor16(nnlm_handle *h, int which)
 {
     const double *Ym = (which == 1) ? h->W64 : h->H64;
-    const int ldm = (which == 1) ? h->npad : h->mpad;       // leading dimension of the master = padded contraction length
+    const int ldm = (which == 1) ? h->npad : h->mpad; // leading dimension of the master = padded contraction length
     const int plen_true = (which == 1) ? h->n : h->m;
     hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
     absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->maxbits);
     const size_t cnt = (size_t)h->KP * ldm;
     factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, h->maxbits, h->scal_exp + 1, h->Y16);
+}
+static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    const int ldm = (which == 1) ? h->npad : h->mpad;
     const uint32_t *A16 = (which == 1) ? h->A16 : h->A16T;
     const int ldc = (which == 1) ? h->mpad : h->npad;
     switch (h->NKQ) {
@@ -1023,6 +1030,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HIPCHK(h, hipEventRecord(h->ev_factor, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream_g, h->ev_factor, 0));
     // 1. cross product slabs
+    if (h->x16) prepare_factor16(h, which);
     {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
         if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
