@@ -89,6 +89,29 @@ def test_golden_halfstep_fixtures(pname, prec, tol):
             assert it == int(z[key + "_it"]), key
 
 
+@pytest.mark.parametrize("scale_a,scale_f", [(1e20, 1e-10), (1e-6, 1e3), (3.7e5, 1.0), (1.0, 2.3e-4)])  # Grams stay >> TINY_NUM
+def test_half_step_is_insensitive_to_the_magnitudes_of_A_and_the_factors(scale_a, scale_f):
+    """The F32 mode's split-fp16 cross products rescale A (once) and the fixed factor (every half-step) by powers of two
+    (k_xprod16.h): matrices and factors far outside the fp16 range must give the same relative accuracy as O(1) data."""
+    rng = np.random.default_rng(77)
+    n, m, k = 300, 200, 20
+    A = scale_a * rng.random((n, m)) ** 2
+    W0 = np.sqrt(scale_a) / scale_f * rng.random((n, k))
+    H0 = scale_f * np.sqrt(scale_a) * rng.random((k, m))
+    for prec, tol in ((_lib.PREC_F32, 2e-5), (_lib.PREC_F64, 1e-10)):
+        with nnlm_amd.Handle(0, prec) as h:
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0)
+            h.half_step(0, [0, 0, 0], 5, 1e-9, 1)
+            W1, _ = h.get_factors()
+            h.half_step(1, [0, 0, 0], 5, 1e-9, 1)
+            _, H1 = h.get_factors()
+        Wt_ref, _ = ref.update(W0.T.copy(), H0, A.T.copy(), None, [0, 0, 0], 5, 1e-9, 1)
+        H_ref, _ = ref.update(H0.copy(), Wt_ref, A, None, [0, 0, 0], 5, 1e-9, 1)
+        assert np.all(np.isfinite(W1)) and np.all(np.isfinite(H1))
+        assert relF(W1, Wt_ref.T) < tol and relF(H1, H_ref) < tol
+
+
 # ---- the alternating driver ------------------------------------------------------------------------
 @pytest.mark.parametrize("pname,tol", [("f64", 1e-9), ("f32", 1e-4)])
 @pytest.mark.parametrize("case", ["cfg1_scd_mse", "cfg1_lee_mse", "cfg1_scd_mkl", "cfg1_lee_mkl", "cfg1_scd_mse_reg"])
