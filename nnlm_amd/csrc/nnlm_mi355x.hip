@@ -1619,11 +1619,13 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
             HIPCHK(h, hipEventRecord(h->ev_hdone, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_hdone, 0));
             if (i + 1 < max_iter && !h->sharded && method < 3) {
-                // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below); the error
-                // block (one more pass over A) is held back until that half-step's own pass over A is done, so the
-                // two HBM streams do not collide and the error block overlaps the compute-bound sweep instead
+                // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below).  The error block
+                // (one more pass over A) starts together with it: since the cross product became HBM bound (k_xprod16.h) the
+                // two streams of A share the bandwidth, but the error block is then finished before the latency-bound sweep
+                // needs the CUs -- measured +2 % over holding it back until the cross product is done (NNLM_ERR_EARLY=0)
                 CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true));
-                HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
+                static int err_early = getenv("NNLM_ERR_EARLY") ? atoi(getenv("NNLM_ERR_EARLY")) : 1;
+                if (!err_early) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
                 spec_pending = true;
             }
             CHK(errors_launch(h, h->stream_e, true)); // reads W_i, H_i and the active sweep counter (then zeroes it)
