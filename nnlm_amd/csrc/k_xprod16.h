@@ -215,3 +215,201 @@ __global__ __launch_bounds__(256) void a16_transpose_kernel(const float *__restr
         row[64 + jj] = lo;
     }
 }
+
+// ---- cross product of the W half-step + the error block of the PREVIOUS iteration in one pass over A --------------------
+// On a trace iteration the reference evaluates  mse = mean((A - W H)^2)  and the KL term  mean(WH - (A+eps) log(WH+eps))
+// (src/nnmf.cpp:135-140) -- one more pass over A.  The W half-step that follows streams A anyway (as A16T: 128 rows i per
+// block, 64 columns j per stage) with H as its fixed factor, and W is not touched until its sweep: so  W H  for the tile in
+// LDS costs 3 more fp16 MFMAs per 16 x 16 x 32 (as cheap as the cross product's own) and the two sums ride along.
+//   * W rows of the block: kq-contiguous split copy W16c [npad][2][64], held in registers (A operand, M = i, K = kq);
+//   * H columns of the stage: kq-contiguous split copy H16c [mpad][2][64], a third LDS image (B operand, N = j);
+//   * a(i, j) is rebuilt from the hi/lo halves already in the A image (hi + lo * 2^-11: 22 bits);
+//   * the two sums: fp32 over the 16 elements of a lane per stage, fp64 across stages, one pair per block in `partial`.
+// Ring of 2 stages (3 images of 32 + 16 + 16 KB each).  No missing values, no masks on A (host falls back to errors_f32_kernel).
+#define XPROD16_ERR_BUF (XPROD_A_IMG_BYTES + 64 * XPROD_ROWB + 64 * XPROD_ROWB)
+template <int NKQ>
+__global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32_t *__restrict__ A16, int lda, const uint32_t *__restrict__ Y16, int ldy,
+                                                                    const uint32_t *__restrict__ H16c, const uint32_t *__restrict__ W16c,
+                                                                    double *__restrict__ Cx, int ldc, size_t slab_stride, int stage_begin,
+                                                                    int stage_end, int stages_per_split, const int *__restrict__ scal_exp,
+                                                                    const int *__restrict__ w_exp, int n_rows, int n_cols,
+                                                                    double *__restrict__ partial)
+{
+    constexpr int KP = 16 * NKQ;
+    constexpr int FL = XPROD_FLUSH_ELEMS / 64;
+    constexpr int YOFF = XPROD_A_IMG_BYTES, HOFF = XPROD_A_IMG_BYTES + 64 * XPROD_ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[2][XPROD_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int i0 = blockIdx.x * XPROD_TN_BJ;
+    int st0 = stage_begin + blockIdx.y * stages_per_split;
+    int st1 = st0 + stages_per_split;
+    if (st1 > stage_end) st1 = stage_end;
+
+    f32x4 accm[NKQ], accx[NKQ];
+    f64x4 acc64[NKQ];
+#pragma unroll
+    for (int b = 0; b < NKQ; b++) {
+        accm[b] = f32x4{0, 0, 0, 0};
+        accx[b] = f32x4{0, 0, 0, 0};
+        acc64[b] = f64x4{0, 0, 0, 0};
+    }
+    // this wave's 16 rows of W, kq-contiguous: lane (l15 = row, lg) holds kq = 32c + 8lg .. +7 of both halves
+    xh8 wh[2], wl[2];
+    {
+        const _Float16 *wrow = (const _Float16 *)(W16c + (size_t)(i0 + 16 * wave + l15) * 64);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            wh[c] = *(const xh8 *)(wrow + 32 * c + 8 * lg);
+            wl[c] = *(const xh8 *)(wrow + 64 + 32 * c + 8 * lg);
+        }
+    }
+    const float ca = ldexpf(1.0f, -scal_exp[0]);                    // a      = (hi + lo/2048) * ca
+    const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1]));      // (W H)  = (main + cross/2048) * cwh
+    double s2 = 0.0, skl = 0.0;
+
+    auto issue = [&](int st, unsigned char *buf) {
+        const size_t c0 = (size_t)st * 64;
+#pragma unroll
+        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(A16 + (size_t)(i0 + row) * lda + c0 + s * 4, buf + t * 1024);
+        }
+#pragma unroll
+        for (int t = wave; t < KP / 4; t += XPROD_WAVES) {
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(Y16 + (size_t)row * ldy + c0 + s * 4, buf + YOFF + t * 1024);
+        }
+#pragma unroll
+        for (int t = wave; t < 16; t += XPROD_WAVES) { // 64 columns j of the stage, 256 bytes (64 hi | 64 lo over kq) each
+            const int row = 4 * t + lg;
+            const int s = l15 ^ (row & 15);
+            glds16(H16c + (c0 + row) * 64 + s * 4, buf + HOFF + t * 1024);
+        }
+    };
+    if (st0 < st1) issue(st0, smem);
+    int since_flush = 0;
+    for (int st = st0; st < st1; ++st) {
+        unsigned char *buf = smem + ((st - st0) & 1) * XPROD16_ERR_BUF;
+        wait_vmcnt(0);
+        __builtin_amdgcn_s_barrier();
+        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * XPROD16_ERR_BUF);
+        f32x4 em[4], ex[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) em[t] = f32x4{0, 0, 0, 0}, ex[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            const int arow = 16 * wave + l15;
+            const int sh = (4 * c2 + lg), sl = 8 + 4 * c2 + lg;
+            const xh8 ah = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sh ^ l15) * 16));
+            const xh8 al = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sl ^ l15) * 16));
+#pragma unroll
+            for (int nt = 0; nt < NKQ; nt++) {
+                const unsigned char *yrow = buf + YOFF + (16 * nt + l15) * XPROD_ROWB;
+                const xh8 yh = *(const xh8 *)(yrow + ((sh ^ l15) * 16));
+                const xh8 yl = *(const xh8 *)(yrow + ((sl ^ l15) * 16));
+                accm[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, accm[nt], 0, 0, 0);
+                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, accx[nt], 0, 0, 0);
+                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, accx[nt], 0, 0, 0);
+            }
+            // W H for this wave's 16 rows x the stage's 64 columns (contraction over kq = 32*c2 ..)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const unsigned char *hrow = buf + HOFF + (16 * t + l15) * XPROD_ROWB;
+                const xh8 hh = *(const xh8 *)(hrow + ((sh ^ l15) * 16));
+                const xh8 hl = *(const xh8 *)(hrow + ((sl ^ l15) * 16));
+                em[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c2], hh, em[t], 0, 0, 0);
+                ex[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c2], hl, ex[t], 0, 0, 0);
+                ex[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c2], hh, ex[t], 0, 0, 0);
+            }
+        }
+        // the two sums over the 16 x 64 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r
+        {
+            float p2 = 0.f, pk = 0.f;
+            const bool interior = (i0 + XPROD_TN_BJ <= n_rows) && (st * 64 + 64 <= n_cols);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * wave + 4 * lg + r, jj = 16 * t + l15;
+                    const unsigned char *arow = buf + row * XPROD_ROWB;
+                    const _Float16 hi = *(const _Float16 *)(arow + ((((jj >> 3)) ^ (row & 15)) * 16) + (jj & 7) * 2);
+                    const _Float16 lo = *(const _Float16 *)(arow + (((8 + (jj >> 3)) ^ (row & 15)) * 16) + (jj & 7) * 2);
+                    const float aa = ((float)hi + (float)lo * (1.0f / XPROD16_LO_SCALE)) * ca;
+                    const float ah2 = (em[t][r] + ex[t][r] * (1.0f / XPROD16_LO_SCALE)) * cwh;
+                    const float d = aa - ah2;
+                    float t2 = d * d;
+                    float tk = __builtin_fmaf(-(aa + (float)NNLM_TINY), __logf(ah2 + (float)NNLM_TINY), ah2);
+                    if (!interior) {
+                        const bool valid = (i0 + row < n_rows) && (st * 64 + jj < n_cols);
+                        if (!valid) t2 = 0.f, tk = 0.f;
+                    }
+                    p2 += t2;
+                    pk += tk;
+                }
+            s2 += (double)p2;
+            skl += (double)pk;
+        }
+        if (++since_flush == FL) {
+            since_flush = 0;
+#pragma unroll
+            for (int b = 0; b < NKQ; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc64[b][r] += (double)accm[b][r] + (double)accx[b][r] * (1.0 / XPROD16_LO_SCALE);
+                accm[b] = f32x4{0, 0, 0, 0};
+                accx[b] = f32x4{0, 0, 0, 0};
+            }
+        }
+    }
+    const double unscale = ldexp(1.0, -(scal_exp[0] + scal_exp[1]));
+    double *out = Cx + (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int nt = 0; nt < NKQ; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kq = 16 * nt + l15;
+            const int j = i0 + 16 * wave + 4 * lg + r;
+            const double v = acc64[nt][r] + (double)accm[nt][r] + (double)accx[nt][r] * (1.0 / XPROD16_LO_SCALE);
+            out[(size_t)kq * ldc + j] = v * unscale;
+        }
+    s2 = wave_sum(s2);
+    skl = wave_sum(skl);
+    if (lane == 0) red[0][wave] = s2, red[1][wave] = skl;
+    __syncthreads();
+    if (tid == 0) {
+        double a2 = 0.0, ak = 0.0;
+        for (int w = 0; w < XPROD_WAVES; w++) a2 += red[0][w], ak += red[1][w];
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial[2 * blk] = a2;
+        partial[2 * blk + 1] = ak;
+    }
+}
+
+// X16c [cols][2][64]: kq-contiguous split copy of the fp64 master X [KP][ld]; one block per 64 columns, transposed through LDS
+// so that both the reads (along the columns) and the writes (256 bytes per column) are contiguous
+__global__ __launch_bounds__(256) void factor16c_kernel(const double *__restrict__ X, int ld, int ncols, int k, const unsigned *__restrict__ maxbits,
+                                                        int *__restrict__ exp_out, uint32_t *__restrict__ X16c)
+{
+    __shared__ float tile[64][65]; // [kq][column]
+    const int e = split16_exponent(__uint_as_float(*maxbits));
+    const float scale = ldexpf(1.0f, e);
+    const int c0 = blockIdx.x * 64;
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+        const int q = t >> 6, c = t & 63;
+        tile[q][c] = (q < k && c0 + c < ncols) ? (float)X[(size_t)q * ld + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+        const int c = t >> 6, q = t & 63;
+        _Float16 hi, lo;
+        split16(tile[q][c], scale, hi, lo);
+        _Float16 *row = (_Float16 *)(X16c + (size_t)(c0 + c) * 64);
+        row[q] = hi;
+        row[64 + q] = lo;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && exp_out) *exp_out = e;
+}

@@ -97,7 +97,10 @@ struct nnlm_handle {
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
     unsigned *maxbits = nullptr; // device: bit pattern of max|factor| (absmax_f64_kernel)
-    int *scal_exp = nullptr;     // device: {eA, eY}
+    int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
+    uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
+    bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
+    int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
     // profiling
@@ -264,12 +267,12 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->maxbits, sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 2 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&h->maxbits, sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
     hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
-    hipMemsetAsync(h->scal_exp, 0, 2 * sizeof(int), h->stream);
+    hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
     hipStreamSynchronize(h->stream);
     h->x16 = x16_enabled(precision);
     *out = h;
@@ -293,7 +296,9 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Hmask);
     hipFree(h->Cx);
     hipFree(h->Y16);
-    h->Y16 = nullptr;
+    hipFree(h->W16c);
+    hipFree(h->H16c);
+    h->Y16 = h->W16c = h->H16c = nullptr;
     hipFree(h->gslabs);
     hipFree(h->red);
     hipFree(h->pack_send);
@@ -560,7 +565,11 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         // split-K slabs: sized for the worst case over ranks (nranks = 1 gives the largest S)
         const HalfPlan ph = plan_half(h, 1, 0, 1), pw = plan_half(h, 0, 0, 1);
         size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
-        if (h->x16) HIPCHK(h, hipMalloc(&h->Y16, (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad) * 4 + 4096));
+        if (h->x16) {
+            HIPCHK(h, hipMalloc(&h->Y16, (size_t)h->KP * (h->npad > h->mpad ? h->npad : h->mpad) * 4 + 4096));
+            HIPCHK(h, hipMalloc(&h->W16c, (size_t)h->npad * 64 * 4 + 4096));
+            HIPCHK(h, hipMalloc(&h->H16c, (size_t)h->mpad * 64 * 4 + 4096));
+        }
         h->Cx_elems = eh > ew ? eh : ew;
         HIPCHK(h, hipMalloc(&h->Cx, h->Cx_elems * 8));
         HIPCHK(h, hipMemset(h->Cx, 0, h->Cx_elems * 8)); // rows >= k of a slab are never written: keep them finite
@@ -708,9 +717,35 @@ static void prepare_factor16(nnlm_handle *h, int which)
     absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->maxbits);
     const size_t cnt = (size_t)h->KP * ldm;
     factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, h->maxbits, h->scal_exp + 1, h->Y16);
+    if (which == 0 && h->fuse_err) { // the fused error block also needs H and W with kq contiguous (same exponent for H)
+        factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, h->maxbits, nullptr, h->H16c);
+        hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
+        absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits);
+        factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits, h->scal_exp + 2, h->W16c);
+    }
+}
+template <int NKQ>
+static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
+{
+    dim3 grid(p.tiles_x, p.S);
+    const int lds = 2 * XPROD16_ERR_BUF;
+    hipFuncSetAttribute((const void *)xprod16_err_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    xprod16_err_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
+                                                                     (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
+                                                                     h->scal_exp + 2, h->n, h->m, h->partials);
+    h->fused_nb = p.tiles_x * p.S;
 }
 static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
 {
+    if (which == 0 && h->fuse_err) {
+        switch (h->NKQ) {
+        case 1: launch_xprod16_err_m<1>(h, p); break;
+        case 2: launch_xprod16_err_m<2>(h, p); break;
+        case 3: launch_xprod16_err_m<3>(h, p); break;
+        default: launch_xprod16_err_m<4>(h, p); break;
+        }
+        return;
+    }
     const int ldm = (which == 1) ? h->npad : h->mpad;
     const uint32_t *A16 = (which == 1) ? h->A16 : h->A16T;
     const int ldc = (which == 1) ? h->mpad : h->npad;
@@ -1313,10 +1348,16 @@ extern "C" int nnlm_sync(nnlm_handle *h)
 // ---------------------------------------------------------------------------------------------
 // Enqueue the error block on stream `st` for the CURRENT factors (pointers captured now); the 8 sums and, when
 // `with_sweeps`, the active sweep counter land in the pinned host_res[0..8]; ev_err fires when they are there.
-static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps)
+// fused_nb > 0: the two sums were left as fused_nb partial pairs in h->partials by the cross product of the speculative
+// W half-step (xprod16_err_kernel); only their reduction, the penalties and the counters remain.
+static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb = 0)
 {
     const int k4 = round_up_i(h->k, 4);
-    {
+    if (fused_nb > 0) {
+        ProfScope ps(h, P_ERRORS, st);
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_xdone, 0));
+        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)fused_nb, 2, h->scal);
+    } else {
         ProfScope ps(h, P_ERRORS, st);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
         size_t nb;
@@ -1623,12 +1664,25 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // (one more pass over A) starts together with it: since the cross product became HBM bound (k_xprod16.h) the
                 // two streams of A share the bandwidth, but the error block is then finished before the latency-bound sweep
                 // needs the CUs -- measured +2 % over holding it back until the cross product is done (NNLM_ERR_EARLY=0)
-                CHK(half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true));
+                // Split-fp16 mode without missing values: that half-step's cross product streams A with H_i as its fixed
+                // factor while W_i is still current, so it evaluates the error sums of (W_i, H_i) on the way
+                // (xprod16_err_kernel) and no separate pass over A is needed (NNLM_ERR_FUSED=0: separate kernel).
+                static int fused_ok = getenv("NNLM_ERR_FUSED") ? atoi(getenv("NNLM_ERR_FUSED")) : 1;
+                h->fuse_err = fused_ok && h->x16 && !h->any_missing;
+                h->fused_nb = 0;
+                rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true);
+                h->fuse_err = false;
+                if (rc != NNLM_OK) {
+                    g_last_error = h->err;
+                    return rc;
+                }
                 static int err_early = getenv("NNLM_ERR_EARLY") ? atoi(getenv("NNLM_ERR_EARLY")) : 1;
                 if (!err_early) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
                 spec_pending = true;
-            }
-            CHK(errors_launch(h, h->stream_e, true)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            } else
+                h->fused_nb = 0;
+            CHK(errors_launch(h, h->stream_e, true, h->fused_nb)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            h->fused_nb = 0;
             // H (and the fp32 copy the error kernel reads) must not be rewritten before the error block is done
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_err, 0));
             double mse, kl, pen[6];

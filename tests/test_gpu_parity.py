@@ -399,7 +399,12 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
     assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
     for key in ("mse_error", "mkl_error", "target_error", "average_epoch"):
-        assert np.array_equal(a[6][key], b[6][key]), key
+        if pname == "f32" and key != "average_epoch":
+            # the plain F32 path evaluates the error sums inside the speculative cross product (xprod16_err_kernel, A rebuilt
+            # from its split-fp16 copy), the sharded path with the separate kernel on the fp32 copy: same sums, other rounding
+            assert np.allclose(a[6][key], b[6][key], rtol=1e-6, atol=0), key
+        else:
+            assert np.array_equal(a[6][key], b[6][key]), key
     assert np.array_equal(b[1][Hm], H0[Hm])
 
 
