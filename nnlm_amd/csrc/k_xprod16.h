@@ -266,6 +266,13 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
             wl[c] = *(const xh8 *)(wrow + 64 + 32 * c + 8 * lg);
         }
     }
+    // one-hot B operands that move the A fragment (M = row, K = 32 columns) into the accumulator layout of W H:
+    // ident[u][k] = 1 iff column k of the K chunk is column 16u + n of the lane's 16-column tile (n = l15)
+    xh8 ident[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) ident[u][e] = (8 * lg + e == 16 * u + l15) ? (_Float16)1.0f : (_Float16)0.0f;
     const float ca = ldexpf(1.0f, -scal_exp[0]);                    // a      = (hi + lo/2048) * ca
     const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1]));      // (W H)  = (main + cross/2048) * cwh
     double s2 = 0.0, skl = 0.0;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
         wait_vmcnt(0);
         __builtin_amdgcn_s_barrier();
         if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * XPROD16_ERR_BUF);
-        f32x4 em[4], ex[4];
+        f32x4 em[4], ex[4], dh[4], dl[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) em[t] = f32x4{0, 0, 0, 0}, ex[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -316,6 +323,12 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                 accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, accx[nt], 0, 0, 0);
                 accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, accx[nt], 0, 0, 0);
             }
+            // a(i, j) of this wave's rows in the accumulator layout (exact: one product with 1.0 per element)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                dh[2 * c2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ident[u], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                dl[2 * c2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ident[u], f32x4{0, 0, 0, 0}, 0, 0, 0);
+            }
             // W H for this wave's 16 rows x the stage's 64 columns (contraction over kq = 32*c2 ..)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -327,32 +340,34 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                 ex[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c2], hh, ex[t], 0, 0, 0);
             }
         }
-        // the two sums over the 16 x 64 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r
+        // the two sums over the 16 x 64 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r (vector arithmetic over
+        // r so that the multiplies and adds pair up into v_pk_*_f32)
         {
-            float p2 = 0.f, pk = 0.f;
+            f32x4 p2 = f32x4{0, 0, 0, 0}, pk = f32x4{0, 0, 0, 0};
             const bool interior = (i0 + XPROD_TN_BJ <= n_rows) && (st * 64 + 64 <= n_cols);
+            const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < 4; t++) {
+                const f32x4 aa = (dh[t] + dl[t] * il) * ca;
+                const f32x4 ah2 = (em[t] + ex[t] * il) * cwh;
+                const f32x4 d = aa - ah2;
+                f32x4 lg4;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = 16 * wave + 4 * lg + r, jj = 16 * t + l15;
-                    const unsigned char *arow = buf + row * XPROD_ROWB;
-                    const _Float16 hi = *(const _Float16 *)(arow + ((((jj >> 3)) ^ (row & 15)) * 16) + (jj & 7) * 2);
-                    const _Float16 lo = *(const _Float16 *)(arow + (((8 + (jj >> 3)) ^ (row & 15)) * 16) + (jj & 7) * 2);
-                    const float aa = ((float)hi + (float)lo * (1.0f / XPROD16_LO_SCALE)) * ca;
-                    const float ah2 = (em[t][r] + ex[t][r] * (1.0f / XPROD16_LO_SCALE)) * cwh;
-                    const float d = aa - ah2;
-                    float t2 = d * d;
-                    float tk = __builtin_fmaf(-(aa + (float)NNLM_TINY), __logf(ah2 + (float)NNLM_TINY), ah2);
-                    if (!interior) {
-                        const bool valid = (i0 + row < n_rows) && (st * 64 + jj < n_cols);
-                        if (!valid) t2 = 0.f, tk = 0.f;
+                for (int r = 0; r < 4; r++) lg4[r] = __logf(ah2[r] + tiny);
+                f32x4 t2 = d * d;
+                f32x4 tk = ah2 - (aa + tiny) * lg4;
+                if (!interior) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool valid = (i0 + 16 * wave + 4 * lg + r < n_rows) && (st * 64 + 16 * t + l15 < n_cols);
+                        if (!valid) t2[r] = 0.f, tk[r] = 0.f;
                     }
-                    p2 += t2;
-                    pk += tk;
                 }
-            s2 += (double)p2;
-            skl += (double)pk;
+                p2 += t2;
+                pk += tk;
+            }
+            s2 += (double)((p2[0] + p2[1]) + (p2[2] + p2[3]));
+            skl += (double)((pk[0] + pk[1]) + (pk[2] + pk[3]));
         }
         if (++since_flush == FL) {
             since_flush = 0;
