@@ -177,6 +177,10 @@ def main():
     dom_ms = kern[dom]["ms_per_launch"]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     x16 = s == 4 and os.environ.get("NNLM_XPROD", "") != "f32"   # split-fp16 cross products: one kernel for both half-steps
+    if x16:  # the W half-step's launches mix xprod16_tn_kernel with the fused cross-product + error-block kernel: price the pure one
+        dom, dom_bytes = "xprod_h", bytes_h
+        dom_ms = kern[dom]["ms_per_launch"]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     kname = "xprod16_tn_kernel" if x16 else ("xprod_nt_kernel" if dom == "xprod_w" else "xprod_tn_kernel")
     traffic, traffic_src = pmc_traffic(kname) if world == 1 else (None, None)
     roofline = dict(bound="hbm", kernel=f"{dom} ({kname})", achieved=achieved,
