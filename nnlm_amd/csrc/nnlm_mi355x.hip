@@ -459,21 +459,24 @@ extern "C" int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_
 // ---------------------------------------------------------------------------------------------
 // factors
 // ---------------------------------------------------------------------------------------------
-// Split-K factor S for tiles_x output tiles: the xprod kernels run one 4-wave block per CU (their LDS ring fills the
-// CU), so the launch executes in ceil(blocks/256) rounds; pick the S (<= 16, each split at least 8 stages deep) whose
-// last round is fullest, preferring fewer slabs on ties.
+// Split-K factor S for tiles_x output tiles.  The cross-product kernels run one block per CU (their LDS ring fills the
+// CU), so a launch executes in ceil(blocks/256) rounds of ceil(stages/S) stages each; every block also pays ~3 stage
+// times of pipeline fill/drain, and every slab costs fp64 writes here and fp64 reads in the solver that sums the slabs
+// (S = 16 instead of 3 at config 2 made the sweep's start-up 0.06 ms longer -- measured).  Pick the cheapest S <= 16.
 static int split_plan(int tiles_x, int stages, int *S, int *sps)
 {
     const int cus = 256;
+    static int smax = getenv("NNLM_SPLIT_MAX") ? atoi(getenv("NNLM_SPLIT_MAX")) : 16;
     int best_s = 1;
-    double best_eff = -1.0;
-    for (int s = 1; s <= 16; s++) {
+    double best_cost = 1e300;
+    for (int s = 1; s <= smax; s++) {
         if (s > 1 && stages / s < 8) break;
         const long blocks = (long)tiles_x * s;
         const long rounds = (blocks + cus - 1) / cus;
-        const double eff = (double)blocks / (double)(rounds * cus);
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
+        const int per_block = (stages + s - 1) / s;
+        const double cost = (double)rounds * (per_block + 3) + 0.75 * s;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
             best_s = s;
         }
     }
