@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256) void na_gram_kernel(const uint32_t *__restrict
 
 // One wavefront per column, lane = coordinate (k <= 64).  a.Graw is either one shared Gram (g_stride = 0) or the
 // per-column Grams (g_stride = KPg*KPg).  Same arithmetic as sweep_ls_kernel (k_sweep.h).
+// value of lane `src` (wave-uniform) in every lane: two v_readlane_b32 instead of a cross-lane LDS permute
+__device__ static inline double readlane_f64(double v, int src)
+{
+    int2 p = __builtin_bit_cast(int2, v);
+    p.x = __builtin_amdgcn_readlane(p.x, src);
+    p.y = __builtin_amdgcn_readlane(p.y, src);
+    return __builtin_bit_cast(double, p);
+}
+
 template <int NKQ, int METHOD>
 __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, size_t g_stride)
 {
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
         if (a.r1 != 0) gd += a.r1;
         gd += NNLM_TINY;
     }
+    const double rgd = 1.0 / gd; // x - mu/G[q][q] through the reciprocal + one Markstein correction (correctly rounded, k_sweep.h)
     double x = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
     double cv = 0.0;
     if (lv)
@@ -206,19 +216,22 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
                 for (int e = 0; e < qend; e++) {
                     const int q = 8 * c + e;
                     if ((mword >> q) & 1ull) continue; // wave uniform
-                    const double xq = __shfl(x, q, 64);
                     if (METHOD == 1) {
-                        const double muq = __shfl(v, q, 64), gqq = __shfl(gd, q, 64);
-                        double tmp = xq - muq / gqq;
-                        if (tmp < 0) tmp = 0;
+                        const double xq = readlane_f64(x, q), muq = readlane_f64(v, q), gqq = readlane_f64(gd, q), rq = readlane_f64(rgd, q);
+                        const double q0 = muq * rq;
+                        const double rr = __builtin_fma(-q0, gqq, muq);
+                        const double quo = __builtin_fma(rr, rq, q0); // = mu / G[q][q], correctly rounded
+                        const double tmp = fmax(xq - quo, 0.0);
                         if (tmp != xq) { // uniform
                             const double d = tmp - xq;
                             v = __builtin_fma(d, g[c][e], v);
-                            const double er = 2 * fabs(xq - tmp) / (tmp + xq + NNLM_TINY);
-                            if (er > rel) rel = er;
+                            // rel-change test without a division: rel only matters through "rel > rel_tol" (k_sweep.h)
+                            if (2 * fabs(d) > a.rel_tol * (tmp + xq + NNLM_TINY)) rel = 1.0 + fabs(a.rel_tol);
                             if (lane == q) x = tmp;
                         }
                     } else {
+                        const double xq = __shfl(x, q, 64);
+                        (void)xq;
                         const double dot = wave_sum(lv ? g[c][e] * x : 0.0);
                         double tmp = dot + a.r2;
                         tmp = __shfl(v, q, 64) / (tmp + NNLM_TINY);
