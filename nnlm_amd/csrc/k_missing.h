@@ -255,3 +255,108 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-column Gram on the fp64 matrix cores over PRECOMPUTED row lists.
+// The missing pattern of A does not change between iterations, so the rows a column's Gram sums over (the missing rows
+// when at most half are missing -- G_j = G_full - sum, otherwise the present rows) are compacted once per matrix into
+// CSR lists (na_count_kernel / na_fill_kernel); na_gram_mfma_kernel then runs one wavefront per column:
+// four listed rows per step, lane (l15, lg) loads Yrow[row_lg][16t + l15] for each 16-wide tile t (128-byte segments of
+// four rows), and one v_mfma_f64_16x16x4_f64 per upper tile pair accumulates  sum_r y_r y_r^T  (the same register is
+// the A operand of tile a and the B operand of tile b).  2 k^2 len flops per column at the fp64 MFMA rate instead of the
+// 4x4-register-block VALU loop of na_gram_kernel (which also re-compacts the index list every launch).
+__global__ __launch_bounds__(256) void na_count_kernel(const uint32_t *__restrict__ bits_all, int words, int p, int ncols, uint32_t *__restrict__ cnt)
+{
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (col >= ncols) return;
+    const uint32_t *bits = bits_all + (size_t)col * words;
+    int c = 0;
+    for (int w = lane; w < (p + 31) / 32; w += 64) {
+        uint32_t v = bits[w];
+        if ((w + 1) * 32 > p) v &= (p & 31) ? ((1u << (p & 31)) - 1u) : 0xFFFFFFFFu;
+        c += __popc(v);
+    }
+    c = (int)wave_sum_ll(c);
+    if (lane == 0) cnt[col] = (uint32_t)c;
+}
+
+// idx[ptr[col] .. ptr[col] + len) = the listed rows of column col in increasing order; meta[col] = len | complement << 31
+__global__ __launch_bounds__(256) void na_fill_kernel(const uint32_t *__restrict__ bits_all, int words, int p, const uint32_t *__restrict__ ptr,
+                                                      const uint32_t *__restrict__ meta, int *__restrict__ idx)
+{
+    __shared__ int wcnt[4];
+    __shared__ int base_s;
+    const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *bits = bits_all + (size_t)col * words;
+    const uint32_t want = (meta[col] >> 31) ? 1u : 0u; // complement: list the missing rows
+    int *out = idx + ptr[col];
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < p; b0 += 256) {
+        const int i = b0 + tid;
+        bool take = false;
+        if (i < p) take = ((bits[i >> 5] >> (i & 31)) & 1u) == want;
+        const unsigned long long bal = __ballot(take);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        if (take) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+}
+
+template <int NKQ>
+__global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
+                                                           const double *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
+                                                           int ncols)
+{
+    constexpr int KP = 16 * NKQ;
+    constexpr int NP = NKQ * (NKQ + 1) / 2;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= ncols) return; // whole wave
+    const uint32_t mt = meta[col];
+    const int len = (int)(mt & 0x7FFFFFFFu);
+    const bool complement = (mt >> 31) != 0;
+    const int *rows = idx + ptr[col];
+
+    f64x4 acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) acc[i] = f64x4{0, 0, 0, 0};
+    double x[NKQ], xn[NKQ];
+    auto load = [&](int g, double (&dst)[NKQ]) {
+        const int r = 4 * g + lg;
+        const int row = (r < len) ? rows[r] : -1;
+#pragma unroll
+        for (int t = 0; t < NKQ; t++) dst[t] = (row >= 0) ? Yrow[(size_t)row * KP + 16 * t + l15] : 0.0;
+    };
+    const int ng = (len + 3) / 4;
+    if (ng > 0) load(0, x);
+    for (int g = 0; g < ng; g++) {
+        if (g + 1 < ng) load(g + 1, xn);
+        int pi = 0;
+#pragma unroll
+        for (int a = 0; a < NKQ; a++)
+#pragma unroll
+            for (int b = a; b < NKQ; b++, pi++) acc[pi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[a], x[b], acc[pi], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NKQ; t++) x[t] = xn[t];
+    }
+    // f64 C/D layout: reg r -> row lg + 4r, col l15; both triangles of the symmetric result
+    double *out = Gcols + (size_t)col * KP * KP;
+    int pi = 0;
+#pragma unroll
+    for (int a = 0; a < NKQ; a++)
+#pragma unroll
+        for (int b = a; b < NKQ; b++, pi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * a + lg + 4 * r, j = 16 * b + l15;
+                const double v = complement ? Gfull[i * KP + j] - acc[pi][r] : acc[pi][r];
+                out[i * KP + j] = v;
+                if (a != b) out[j * KP + i] = v;
+            }
+}

@@ -76,6 +76,10 @@ struct nnlm_handle {
     size_t Cx_elems = 0;
     double *gslabs = nullptr, *Graw = nullptr; // Graw = head of red
     double *red = nullptr;               // [KP*KP | KP*max(npad,mpad)]: the buffer one all-reduce sums
+    // NA path: per orientation (0: rows of A for the W half-step, 1: columns for the H half-step) the CSR lists of the rows a
+    // column's Gram sums over (k_missing.h, na_gram_mfma_kernel); built on first use, they live as long as the matrix
+    uint32_t *na_ptr[2] = {nullptr, nullptr}, *na_meta[2] = {nullptr, nullptr};
+    int *na_idx[2] = {nullptr, nullptr};
     double *Yrow = nullptr;              // [max(npad,mpad)][KP] row-major copy of the fixed factor (NA path)
     double *Gcols = nullptr;             // [max(n,m)][KP][KP] per-column Grams (NA path)
     double *partials = nullptr;
@@ -317,6 +321,13 @@ static void free_factors(nnlm_handle *h)
 
 static void free_matrix(nnlm_handle *h)
 {
+    for (int o = 0; o < 2; o++) {
+        hipFree(h->na_ptr[o]);
+        hipFree(h->na_meta[o]);
+        hipFree(h->na_idx[o]);
+        h->na_ptr[o] = h->na_meta[o] = nullptr;
+        h->na_idx[o] = nullptr;
+    }
     hipFree(h->A);
     hipFree(h->A16);
     hipFree(h->A16T);
@@ -962,14 +973,61 @@ static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size
     }
 }
 
-static void launch_na_gram(nnlm_handle *h, const uint32_t *bits, int words, int p, int ncols)
+// CSR row lists of orientation `which` (see nnlm_handle::na_ptr): count, prefix sum on the host (once), fill
+static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols)
 {
+    if (h->na_ptr[which]) return NNLM_OK;
+    uint32_t *cnt = nullptr;
+    HIPCHK(h, hipMalloc(&cnt, (size_t)ncols * 4));
+    na_count_kernel<<<(ncols + 3) / 4, 256, 0, h->stream>>>(bits, words, p, ncols, cnt);
+    std::vector<uint32_t> hc(ncols), hptr(ncols + 1), hmeta(ncols);
+    HIPCHK(h, hipMemcpyAsync(hc.data(), cnt, (size_t)ncols * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(cnt);
+    size_t total = 0;
+    for (int c = 0; c < ncols; c++) {
+        const uint32_t miss = hc[c];
+        const bool complement = (size_t)miss * 2 <= (size_t)p; // sum over the missing rows and subtract from the full Gram
+        const uint32_t len = complement ? miss : (uint32_t)p - miss;
+        hptr[c] = (uint32_t)total;
+        hmeta[c] = len | (complement ? 0x80000000u : 0u);
+        total += len;
+    }
+    hptr[ncols] = (uint32_t)total;
+    if (total >= 0x7FFFFFFFull) return fail(h, NNLM_ERR_UNSUPPORTED, "missing-value row lists exceed 2^31 entries");
+    HIPCHK(h, hipMalloc(&h->na_ptr[which], (size_t)(ncols + 1) * 4));
+    HIPCHK(h, hipMalloc(&h->na_meta[which], (size_t)ncols * 4));
+    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 4) * 4));
+    HIPCHK(h, hipMemcpyAsync(h->na_ptr[which], hptr.data(), (size_t)(ncols + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->na_meta[which], hmeta.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, h->stream));
+    na_fill_kernel<<<ncols, 256, 0, h->stream>>>(bits, words, p, h->na_ptr[which], h->na_meta[which], h->na_idx[which]);
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // hptr / hmeta go out of scope
+    return NNLM_OK;
+}
+
+// NNLM_NA_GRAM=valu keeps the VALU kernel (A/B)
+static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols)
+{
+    static int use_mfma = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "valu") == 0) ? 0 : 1;
+    if (use_mfma) {
+        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
+        if (rc != NNLM_OK) return rc;
+        const int nb = (ncols + 3) / 4;
+        switch (h->NKQ) {
+        case 1: na_gram_mfma_kernel<1><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
+        case 2: na_gram_mfma_kernel<2><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
+        case 3: na_gram_mfma_kernel<3><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
+        default: na_gram_mfma_kernel<4><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
+        }
+        return NNLM_OK;
+    }
     switch (h->NKQ) {
     case 1: na_gram_kernel<1><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
     case 2: na_gram_kernel<2><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
     case 3: na_gram_kernel<3><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
     default: na_gram_kernel<4><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
     }
+    return NNLM_OK;
 }
 
 // KL methods: no Gram, no cross product -- one block per column streams the column of A and the fixed factor.
@@ -1205,7 +1263,10 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             const double *Ymaster = (which == 1) ? h->W64 : h->H64;
             const int ldy = (which == 1) ? h->npad : h->mpad;
             factor_rows_kernel<<<(p_len + 255) / 256, 256, 0, h->stream>>>(Ymaster, ldy, p_len, h->KP, h->Yrow);
-            launch_na_gram(h, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, a.ncols);
+            {
+                int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, a.ncols);
+                if (rcg != NNLM_OK) return rcg;
+            }
             a.Graw = h->Gcols;
             launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
         } else if (a.ncols > a.col0)

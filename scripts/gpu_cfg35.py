@@ -21,9 +21,10 @@ for name, method, inner, reg, na in (("cfg3 lee+mkl", 4, 1, [0, 0, 0], False), (
         h.set_factors(k, W0, H0)
         h.iterate(1, reg, reg, inner, 1e-9, method); h.sync()
         W1, H1 = h.get_factors()
-        h.profile_enable(True)
         its = 3
         t2 = time.perf_counter(); h.iterate(its, reg, reg, inner, 1e-9, method); h.sync(); t3 = time.perf_counter()
+        h.profile_enable(True)  # per-kernel times from a separate pass (HIP events around every scope)
+        h.iterate(its, reg, reg, inner, 1e-9, method); h.sync()
         mse, kl, pen = h.errors()
         line = f"{name}: upload {t1-t0:.2f}s, {1e3*(t3-t2)/its:.2f} ms/iteration, mse {mse:.6f} kl {kl:.6f} |"
         for nm in ("xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors"):
