@@ -205,6 +205,64 @@ __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict
     }
 }
 
+// What[j][i] = sum_q W[q][i] H[q][j] in fp32, stored in the layout of A ([mpad][lda]): the starting state vectors
+// y = Yt^T x of ALL columns of a KL half-step (src/base_algorithms.cpp:81, :129) as one GEMM instead of k passes over the
+// fixed factor per column (k_kl.h).  Same tiling and MFMA phase as errors_f32_kernel.
+__global__ __launch_bounds__(256) void wh_store_kernel(const float *__restrict__ Wf, int ldw, const float *__restrict__ Hf, int ldh, int k2,
+                                                       float *__restrict__ What, int lda)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_err[];
+    float *Ws = (float *)smem_err;          // [k2][128]
+    float *Hs = Ws + (size_t)k2 * ERRF_TILE; // [k2][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * ERRF_TILE, j0 = blockIdx.y * ERRF_TILE;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ib = 64 * (wave & 1), jb = 64 * (wave >> 1);
+    {
+        const int nrow2 = k2 / 2;
+        for (int t = wave; t < 2 * nrow2; t += 4) {
+            const bool isw = t < nrow2;
+            const int tt = isw ? t : t - nrow2;
+            const int row = 2 * tt + (lane >> 5);
+            const float *src = isw ? (Wf + (size_t)row * ldw + i0 + 4 * (lane & 31)) : (Hf + (size_t)row * ldh + j0 + 4 * (lane & 31));
+            glds16(src, (unsigned char *)(isw ? Ws : Hs) + (size_t)tt * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[2][2]; // [tj][ti]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    for (int q = lh; q < k2; q += 2) {
+        float hj[2], wi[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            hj[t] = Hs[(size_t)q * ERRF_TILE + jb + 32 * t + l31];
+            wi[t] = Ws[(size_t)q * ERRF_TILE + ib + 32 * t + l31];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(hj[a], wi[b], acc[a][b], 0, 0, 0);
+    }
+    // D layout 32x32: row M = (r&3) + 8*(r>>2) + 4*(lane>>5) (a column j), column N = lane & 31 (a row i): 128-byte stores
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int i = i0 + ib + 32 * b + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                What[(size_t)j * lda + i] = acc[a][b][r];
+            }
+        }
+}
+
 // Xf[q][c] = (float) X[q][c]: fp32 [kq][col] copy of a factor for errors_f32_kernel.
 __global__ __launch_bounds__(256) void factor_to_f32_kernel(const double *__restrict__ X, size_t count, float *__restrict__ Xf)
 {

@@ -181,6 +181,7 @@ struct KlFastArgs {
     KlArgs a;
     const float *Yf; // [KP][ldyf] fp32 copy of the fixed factor, contraction index fastest
     int ldyf;
+    const float *Yinit; // starting state vectors of all columns in the layout of A (wh_store_kernel); NULL: k passes over Yf
 };
 
 template <int EPT, int METHOD, int C>
@@ -227,22 +228,35 @@ __global__ __launch_bounds__(KL_THREADS) void kl_fast_kernel(const KlFastArgs fa
     double S[C];
 #pragma unroll
     for (int c = 0; c < C; c++) S[c] = 0.0;
-    for (int q = 0; q < k; q++) { // y = Yt^T x, S = sum(x)
-        float w[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int i = e * KL_THREADS + tid;
-            w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
-        }
+    if (fa.Yinit) { // y = Yt^T x was formed for all columns at once by wh_store_kernel
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const double xq = xs[c][q];
-            S[c] += xq;
-            const float xf = (float)xq;
+            const int col = (col0 + c < a.ncols) ? col0 + c : col0;
+            const float *Ycol = fa.Yinit + (size_t)col * a.a_col_stride;
 #pragma unroll
-            for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, xf, y[c][e]);
+            for (int e = 0; e < EPT; e++) {
+                const int i = e * KL_THREADS + tid;
+                y[c][e] = ((vbits[c] >> e) & 1ull) ? Ycol[(size_t)i * a.a_i_stride] : 0.0f;
+            }
+            for (int q = 0; q < k; q++) S[c] += xs[c][q];
         }
-    }
+    } else
+        for (int q = 0; q < k; q++) { // y = Yt^T x, S = sum(x)
+            float w[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = e * KL_THREADS + tid;
+                w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const double xq = xs[c][q];
+                S[c] += xq;
+                const float xf = (float)xq;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, xf, y[c][e]);
+            }
+        }
 
     double rel[C];
     unsigned tdone[C];

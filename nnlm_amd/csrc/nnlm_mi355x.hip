@@ -102,6 +102,7 @@ struct nnlm_handle {
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
     unsigned *maxbits = nullptr; // device: bit pattern of max|factor| (absmax_f64_kernel)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
+    float *What = nullptr;       // [mpad][npad] fp32 W^T H: starting state vectors of a KL half-step (wh_store_kernel), on first use
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
     bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
     int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
@@ -299,6 +300,8 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Wmask);
     hipFree(h->Hmask);
     hipFree(h->Cx);
+    hipFree(h->What);
+    h->What = nullptr;
     hipFree(h->Y16);
     hipFree(h->W16c);
     hipFree(h->H16c);
@@ -1075,14 +1078,27 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         else if (use_kl_fast()) {
             KlFastArgs fa;
             fa.a = a;
+            const size_t cnt = (size_t)h->KP * h->mpad; // [KP][mpad] fp32 copy of H (also used by the error block)
+            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
             if (which == 1) {
                 fa.Yf = (const float *)h->Wop; // the TN operand copy of W: [KP][npad]
                 fa.ldyf = h->npad;
             } else {
-                const size_t cnt = (size_t)h->KP * h->mpad; // [KP][mpad] fp32 copy of H (also used by the error block)
-                factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
                 fa.Yf = h->Hkq;
                 fa.ldyf = h->mpad;
+            }
+            // starting state vectors y = Yt^T x of all columns as ONE GEMM (W^T H in the layout of A) instead of k passes
+            // over the fixed factor per column; NNLM_KL_INIT=rows keeps the per-column passes
+            static int gemm_init = (getenv("NNLM_KL_INIT") && strcmp(getenv("NNLM_KL_INIT"), "rows") == 0) ? 0 : 1;
+            fa.Yinit = nullptr;
+            if (gemm_init) {
+                if (!h->What) HIPCHK(h, hipMalloc(&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096));
+                const int k2 = round_up_i(h->k, 2);
+                const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
+                hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
+                wh_store_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad);
+                fa.Yinit = h->What;
             }
             launch_kl_fast(method, fa, h->stream);
         } else launch_kl<float>(method, a, h->stream);
