@@ -11,9 +11,11 @@
 
 #define GRAM_COLS_PER_BLOCK 256
 
+// maxbits != NULL: also atomicMax the bit pattern of max|x| (as float) over everything the block reads -- the scale of the
+// split-fp16 copy of the same factor (k_xprod16.h) then needs no pass of its own.
 template <int NKQ>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restrict__ X, int ld, int c_begin, int c_end,
-                                                           double *__restrict__ slabs)
+                                                           double *__restrict__ slabs, unsigned *__restrict__ maxbits = nullptr)
 {
     constexpr int KP = 16 * NKQ;
     __shared__ double red[KP * KP]; // waves 3,2,1 fold their tiles here in turn (fixed order)
@@ -27,11 +29,16 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restr
 #pragma unroll
         for (int b = 0; b < NKQ; b++) acc[a][b] = f64x4{0, 0, 0, 0};
 
+    float mx = 0.0f;
     // 8 columns per step: lane holds X[16t + l15][c + 2*lg + e], e = 0,1
     for (int c = c0; c < c0 + 64 && c < c_end; c += 8) {
         f64x2 x[NKQ];
 #pragma unroll
         for (int t = 0; t < NKQ; t++) x[t] = *(const f64x2 *)(X + (size_t)(16 * t + l15) * ld + c + 2 * lg);
+        if (maxbits) {
+#pragma unroll
+            for (int t = 0; t < NKQ; t++) mx = fmaxf(mx, fmaxf(fabsf((float)x[t][0]), fabsf((float)x[t][1])));
+        }
         if (c + 8 > c_end) { // ragged end of a slab range (multi-GPU split): drop columns >= c_end
 #pragma unroll
             for (int t = 0; t < NKQ; t++) {
@@ -46,6 +53,11 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restr
 #pragma unroll
                 for (int b = a; b < NKQ; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[a][e], x[b][e], acc[a][b], 0, 0, 0);
+    }
+    if (maxbits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > 0.0f) atomicMax(maxbits, __float_as_uint(mx));
     }
     // f64 C/D layout: reg r -> row lg + 4r, col l15
     for (int w = 3; w >= 1; --w) {
@@ -128,5 +140,64 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
     } else if (op_mode == 2) {
         if (op_f64) ((double *)op)[(size_t)col * op_ld + q] = v;
         else ((float *)op)[(size_t)col * op_ld + q] = (float)v;
+    }
+}
+
+// gram_reduce + the chain-wave constants of the SCD sweep (k_sweep_wg.h, layout of sweep_consts_kernel) in one launch:
+// 64 outputs per block, four threads per output (slabs g, g+4, ...; folded in a fixed order); the block that finishes last
+// (device counter, reset for the next launch) has all of G in front of it and writes the constants image.
+__global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
+                                                                 int k, double r0, double r1, double *__restrict__ consts,
+                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word)
+{
+    __shared__ double part[4][64];
+    __shared__ int last_s;
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    int a = idx / KP, b = idx % KP;
+    if ((a >> 4) > (b >> 4)) {
+        const int t = a;
+        a = b;
+        b = t;
+    }
+    const size_t src = (size_t)a * KP + b;
+    double s = 0.0;
+    for (int i = g; i < nslabs; i += 4) s += slabs[(size_t)i * KP * KP + src];
+    part[g][e] = s;
+    __syncthreads();
+    if (g == 0) G[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        *counter = 0u;
+        if (zero_word) *zero_word = 0u; // the max word the NEXT half-step's gram_partial accumulates into
+    }
+    const int nbk = (k + 3) / 4;
+    auto edited = [&](int c, int kc) -> double {
+        if (c >= k || kc >= k) return (c == kc) ? 1.0 : 0.0;
+        double v = __builtin_nontemporal_load(G + (size_t)c * KP + kc);
+        if (c == kc && r0 != r1) v += r0 - r1;
+        if (r1 != 0) v += r1;
+        if (c == kc) v += NNLM_TINY;
+        return v;
+    };
+    for (int t = threadIdx.x; t < nbk * 32; t += 256) {
+        const int bb = t / 32, i = t % 32;
+        const int nb = (bb + 1 < nbk) ? bb + 1 : 0;
+        double v = 0.0;
+        if (i < 4) v = 1.0 / edited(4 * bb + i, 4 * bb + i);
+        else if (i < 8) v = edited(4 * bb + i - 4, 4 * bb + i - 4);
+        else if (i < 14) {
+            const int s2[6] = {1, 2, 2, 3, 3, 3}, s1[6] = {0, 0, 1, 0, 1, 2};
+            v = edited(4 * bb + s2[i - 8], 4 * bb + s1[i - 8]);
+        } else if (i >= 16) {
+            const int ss = (i - 16) / 4, gg = (i - 16) % 4;
+            v = (4 * nb + ss < k && 4 * bb + gg < k) ? edited(4 * nb + ss, 4 * bb + gg) : 0.0;
+        }
+        consts[t] = v;
     }
 }

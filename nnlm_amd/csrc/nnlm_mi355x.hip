@@ -100,7 +100,9 @@ struct nnlm_handle {
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
-    unsigned *maxbits = nullptr; // device: bit pattern of max|factor| (absmax_f64_kernel)
+    unsigned *maxbits = nullptr; // device [4]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter
+    int mb_par = 0;
+    bool consts_ready = false;   // sweep_consts image already produced for this half-step (gram_reduce_consts_kernel)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
     float *What = nullptr;       // [mpad][npad] fp32 W^T H: starting state vectors of a KL half-step (wh_store_kernel), on first use
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
@@ -272,12 +274,13 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->maxbits, sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&h->maxbits, 4 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
     hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
     hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
+    hipMemsetAsync(h->maxbits, 0, 4 * sizeof(unsigned), h->stream);
     hipStreamSynchronize(h->stream);
     h->x16 = x16_enabled(precision);
     *out = h;
@@ -725,17 +728,21 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
 // split copy of the fixed factor, scaled by its own power of two (two small kernels, outside the cross product's timing
 // scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
 // made the step SLOWER by 1 % -- the Gram kernels then overlap more of the (now HBM-bound) cross product.
-static void prepare_factor16(nnlm_handle *h, int which)
+// mb: device word that already holds max|factor| (from gram_partial_kernel), or NULL: compute it here
+static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr)
 {
     const double *Ym = (which == 1) ? h->W64 : h->H64;
     const int ldm = (which == 1) ? h->npad : h->mpad; // leading dimension of the master = padded contraction length
     const int plen_true = (which == 1) ? h->n : h->m;
-    hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
-    absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->maxbits);
+    if (!mb) {
+        mb = h->maxbits;
+        hipMemsetAsync(mb, 0, sizeof(unsigned), h->stream);
+        absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, mb);
+    }
     const size_t cnt = (size_t)h->KP * ldm;
-    factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, h->maxbits, h->scal_exp + 1, h->Y16);
+    factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, mb, h->scal_exp + 1, h->Y16);
     if (which == 0 && h->fuse_err) { // the fused error block also needs H and W with kq contiguous (same exponent for H)
-        factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, h->maxbits, nullptr, h->H16c);
+        factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, mb, nullptr, h->H16c);
         hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
         absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits);
         factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits, h->scal_exp + 2, h->W16c);
@@ -859,7 +866,8 @@ static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
     if (method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
         const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
         const bool hm = a.mask != nullptr;
-        sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
+        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
+        h->consts_ready = false;
 #define NNLM_WG_SWEEP(NT_)                                                                                              \
     {                                                                                                                   \
         const int lds = sweep_wg_lds_bytes(NT_);                                                                        \
@@ -1137,6 +1145,40 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         HIPCHK(h, hipMalloc(&h->Gcols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * h->KP * 8));
     }
     const HalfPlan p = plan_half(h, which, h->rank, h->nranks);
+    // Dense SCD half-step of the split-fp16 mode on ONE stream (NNLM_ONE_STREAM=0: the two-stream flow below).  The small
+    // kernels between a sweep and the next cross product cost as much as they overlap (kernel timeline: 47 us from sweep end
+    // to cross product start, 24 us from its end to the next sweep, a third of it cross-stream event latency), so they are
+    // fused instead: gram_partial also yields max|factor| (no absmax pass, no memset), gram_reduce also writes the chain-wave
+    // constants of the sweep (no sweep_consts launch), and nothing waits on another stream.
+    static int one_stream_env = getenv("NNLM_ONE_STREAM") ? atoi(getenv("NNLM_ONE_STREAM")) : 1;
+    h->consts_ready = false;
+    if (one_stream_env && h->x16 && !h->sharded && !h->any_missing && method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
+        unsigned *mb = h->maxbits + 1 + h->mb_par, *mb_next = h->maxbits + 1 + (h->mb_par ^ 1);
+        h->mb_par ^= 1;
+        const double *Ym = (which == 1) ? h->W64 : h->H64;
+        const int ldm = (which == 1) ? h->npad : h->mpad, lim = (which == 1) ? h->n : h->m;
+        int nb = (lim + GRAM_COLS_PER_BLOCK - 1) / GRAM_COLS_PER_BLOCK;
+        if (nb < 1) nb = 1;
+        {
+            ProfScope ps(h, P_GRAM, h->stream);
+            switch (h->NKQ) {
+            case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
+            case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
+            case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
+            default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
+            }
+            prepare_factor16(h, which, mb);
+            gram_reduce_consts_kernel<<<h->KP * h->KP / 64, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw, h->k, reg[0], reg[1], h->sweep_consts,
+                                                                             h->maxbits + 3, mb_next);
+            h->consts_ready = true;
+        }
+        {
+            ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
+            launch_xprod16(h, which, p);
+        }
+        if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream));
+        return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase);
+    }
     // The fixed factor is final once everything already on the main stream has run: the Gram kernels (stream_g) start
     // there and overlap the A-streaming cross product (the xprod launch leaves 19 of 256 CUs idle at config 2).
     HIPCHK(h, hipEventRecord(h->ev_factor, h->stream));
