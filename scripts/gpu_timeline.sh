@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/tl
 cd /tmp
-ITERS=3 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl -o tl -- python $R/scripts/gpu_time.py > $R/gpurun_out/tl/run.log 2>&1
+ITERS=3 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl -o tl -- python $R/scripts/${TL_SCRIPT:-gpu_time.py} > $R/gpurun_out/tl/run.log 2>&1
 cd $R
 python - <<'PY'
 import csv, glob
@@ -12,7 +12,7 @@ f = glob.glob("gpurun_out/tl/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last ~40 kernels = the final iterations
-tail = rows[-46:]
+tail = rows[-int(__import__("os").environ.get("TL_ROWS", "46")):]
 t0 = int(tail[0]["Start_Timestamp"])
 prev_end = None
 for r in tail:
