@@ -1,5 +1,6 @@
+"""BASELINE.json configs[4] (10 % NA + L1/L2) at full size: wall time of successive iterations (no profiling scopes)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nnlm_amd
 from nnlm_amd import _lib
@@ -10,7 +11,8 @@ A.ravel()[np.random.default_rng(7).choice(n * m, n * m // 10, replace=False)] = 
 reg = [0.01, 0, 0.01]
 with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
     h.set_matrix(A); h.set_factors(k, W0, H0)
-    h.iterate(1, reg, reg, 50, 1e-9, 1); h.sync()
-    for its in (1, 3, 10):
-        t2 = time.perf_counter(); h.iterate(its, reg, reg, 50, 1e-9, 1); h.sync(); t3 = time.perf_counter()
-        print(its, "iterations:", round(1e3 * (t3 - t2) / its, 2), "ms/iteration", flush=True)
+    out = []
+    for it in range(8):
+        t2 = time.perf_counter(); h.iterate(1, reg, reg, 50, 1e-9, 1); h.sync(); t3 = time.perf_counter()
+        out.append(f"{1e3 * (t3 - t2):.1f}")
+    print("ms per iteration, iterations 1..8:", " ".join(out), "| sweeps per column so far", h.take_sweeps() / (n + m) / 8, flush=True)
