@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
 // (device counter, reset for the next launch) has all of G in front of it and writes the constants image.
 __global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
                                                                  int k, double r0, double r1, double *__restrict__ consts,
-                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word)
+                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word, int fast)
 {
     __shared__ double part[4][64];
     __shared__ int last_s;
@@ -185,19 +185,5 @@ __global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *_
         if (c == kc) v += NNLM_TINY;
         return v;
     };
-    for (int t = threadIdx.x; t < nbk * 32; t += 256) {
-        const int bb = t / 32, i = t % 32;
-        const int nb = (bb + 1 < nbk) ? bb + 1 : 0;
-        double v = 0.0;
-        if (i < 4) v = 1.0 / edited(4 * bb + i, 4 * bb + i);
-        else if (i < 8) v = edited(4 * bb + i - 4, 4 * bb + i - 4);
-        else if (i < 14) {
-            const int s2[6] = {1, 2, 2, 3, 3, 3}, s1[6] = {0, 0, 1, 0, 1, 2};
-            v = edited(4 * bb + s2[i - 8], 4 * bb + s1[i - 8]);
-        } else if (i >= 16) {
-            const int ss = (i - 16) / 4, gg = (i - 16) % 4;
-            v = (4 * nb + ss < k && 4 * bb + gg < k) ? edited(4 * nb + ss, 4 * bb + gg) : 0.0;
-        }
-        consts[t] = v;
-    }
+    for (int t = threadIdx.x; t < nbk * 32; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / 32, t % 32, fast);
 }

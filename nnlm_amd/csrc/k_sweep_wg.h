@@ -59,8 +59,9 @@ __host__ __device__ static inline int sweep_wg_lds_bytes(int NT)
 //   [8..13]  G[4b+s2][4b+s], s2 > s, in the order (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)        [14,15] unused
 //   [16..31] G[4nb+s][4b+g] at 16 + 4s + g
 // with the regularisation edits of src/update_with_missing.cpp:20-24; padded coordinates: diagonal 1, rest 0.
+// (records are produced by sweep_wg_const, common.h -- shared with gram_reduce_consts_kernel)
 __global__ __launch_bounds__(256) void sweep_consts_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1,
-                                                           double *__restrict__ consts)
+                                                           double *__restrict__ consts, int fast)
 {
     const int nbk = (k + 3) / 4;
     auto edited = [&](int c, int kc) -> double {
@@ -71,21 +72,8 @@ __global__ __launch_bounds__(256) void sweep_consts_kernel(const double *__restr
         if (c == kc) g += NNLM_TINY;
         return g;
     };
-    for (int e = threadIdx.x; e < nbk * SWEEP_WG_CONSTS; e += blockDim.x) {
-        const int b = e / SWEEP_WG_CONSTS, i = e % SWEEP_WG_CONSTS;
-        const int nb = (b + 1 < nbk) ? b + 1 : 0;
-        double v = 0.0;
-        if (i < 4) v = 1.0 / edited(4 * b + i, 4 * b + i);
-        else if (i < 8) v = edited(4 * b + i - 4, 4 * b + i - 4);
-        else if (i < 14) {
-            const int s2[6] = {1, 2, 2, 3, 3, 3}, s[6] = {0, 0, 1, 0, 1, 2};
-            v = edited(4 * b + s2[i - 8], 4 * b + s[i - 8]);
-        } else if (i >= 16) {
-            const int ss = (i - 16) / 4, g = (i - 16) % 4;
-            v = (4 * nb + ss < k && 4 * b + g < k) ? edited(4 * nb + ss, 4 * b + g) : 0.0;
-        }
-        consts[e] = v;
-    }
+    for (int e = threadIdx.x; e < nbk * SWEEP_WG_CONSTS; e += blockDim.x)
+        consts[e] = sweep_wg_const(edited, k, nbk, e / SWEEP_WG_CONSTS, e % SWEEP_WG_CONSTS, fast);
 }
 
 template <int NT, bool HAS_MASK>

@@ -19,6 +19,7 @@
 #include "k_sweep.h"
 #include "k_sweep_mfma.h"
 #include "k_sweep_wg.h"
+#include "k_sweep_wgf.h"
 #include "k_xprod.h"
 #include "k_xprod16.h"
 
@@ -861,23 +862,46 @@ static bool use_wg_sweep()
     return v == 1;
 }
 
+// The restructured sweep (k_sweep_wgf.h: rows of G divided by their diagonal, quotient-free chain, x kept by the update
+// waves) belongs to the fp32-operand mode; the strict fp64 mode keeps k_sweep_wg.h and the reference's arithmetic
+// (correctly rounded mu / G[q][q]).  NNLM_SWEEP_FAST=0 for A/B runs.
+static bool sweep_fast(const nnlm_handle *h)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNLM_SWEEP_FAST");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return h->prec == NNLM_PREC_F32 && v == 1 && h->k > 8; // (x kept by the update waves needs >= 3 blocks of 4 coordinates)
+}
+
+template <int NT, bool HAS_MASK, bool FAST>
+static void launch_sweep_wg(nnlm_handle *h, const SweepArgs &a, int nb)
+{
+    if (FAST) {
+        const int lds = sweep_wgf_lds_bytes(NT);
+        hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        sweep_scd_wgf_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
+    } else {
+        const int lds = sweep_wg_lds_bytes(NT);
+        hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        sweep_scd_wg_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
+    }
+}
+
 static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
     if (method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
         const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
-        const bool hm = a.mask != nullptr;
-        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
+        const bool hm = a.mask != nullptr, fast = sweep_fast(h);
+        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts, fast ? 1 : 0);
         h->consts_ready = false;
 #define NNLM_WG_SWEEP(NT_)                                                                                              \
     {                                                                                                                   \
-        const int lds = sweep_wg_lds_bytes(NT_);                                                                        \
-        if (hm) {                                                                                                       \
-            hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
-            sweep_scd_wg_kernel<NT_, true><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);               \
-        } else {                                                                                                        \
-            hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            sweep_scd_wg_kernel<NT_, false><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);              \
-        }                                                                                                               \
+        if (hm && fast) launch_sweep_wg<NT_, true, true>(h, a, nb);                                                     \
+        else if (hm) launch_sweep_wg<NT_, true, false>(h, a, nb);                                                       \
+        else if (fast) launch_sweep_wg<NT_, false, true>(h, a, nb);                                                     \
+        else launch_sweep_wg<NT_, false, false>(h, a, nb);                                                              \
     }
         switch (h->NKQ) {
         case 1: NNLM_WG_SWEEP(1) break;
@@ -1169,7 +1193,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             }
             prepare_factor16(h, which, mb);
             gram_reduce_consts_kernel<<<h->KP * h->KP / 64, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw, h->k, reg[0], reg[1], h->sweep_consts,
-                                                                             h->maxbits + 3, mb_next);
+                                                                             h->maxbits + 3, mb_next, sweep_fast(h) ? 1 : 0);
             h->consts_ready = true;
         }
         {

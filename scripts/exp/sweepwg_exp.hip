@@ -1,14 +1,23 @@
 // Standalone check + timing of sweep_scd_wg_kernel against sweep_scd_mfma_kernel (not part of the product).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o sweepwg_exp sweepwg_exp.hip ; ./sweepwg_exp [ncols] [k] [max_iter]
 #define SWEEP_WG_TIMING 1
+#ifndef FASTV
+#define FASTV true
+#endif
 #include "../../nnlm_amd/csrc/k_sweep_mfma.h"
 #include "../../nnlm_amd/csrc/k_sweep_wg.h"
+#include "../../nnlm_amd/csrc/k_sweep_wgf.h"
 #include <cstdio>
 #include <cmath>
 #include <vector>
 #include <random>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+#if FASTV
+#define WGK sweep_scd_wgf_kernel
+#else
+#define WGK sweep_scd_wg_kernel
+#endif
 template <int NT> static int run(int ncols, int k, int max_iter)
 {
     const int KP = 16 * NT;
@@ -27,9 +36,9 @@ template <int NT> static int run(int ncols, int k, int max_iter)
     CK(hipMemset(dO1, 0, X.size() * 8)); CK(hipMemset(dO2, 0, X.size() * 8));
     SweepArgs a{};
     a.X = dX; a.ldx = ld; a.ldo = ld; a.ocol0 = 0; a.col0 = 0; a.Graw = dG; a.KPg = KP; a.Cx = dC; a.slab_stride = (size_t)KP * ld; a.nslabs = 1; a.ldc = ld;
-    a.ncols = ncols; a.k = k; a.r0 = 0.02; a.r1 = 0.01; a.r2 = 0.03; a.mask = nullptr; a.max_iter = max_iter; a.rel_tol = 1e-9; a.op = nullptr; a.op_mode = 0; a.sweeps = dS;
-    const int lds = sweep_wg_lds_bytes(NT);
-    CK(hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    a.ncols = ncols; a.k = k; a.r0 = 0.02; a.r1 = 0.01; a.r2 = 0.03; a.mask = nullptr; a.max_iter = max_iter; a.rel_tol = getenv("REL_TOL") ? atof(getenv("REL_TOL")) : 1e-9; a.op = nullptr; a.op_mode = 0; a.sweeps = dS;
+    const int lds = FASTV ? sweep_wgf_lds_bytes(NT) : sweep_wg_lds_bytes(NT);
+    CK(hipFuncSetAttribute((const void *)WGK<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms1 = 0, ms2 = 0;
     for (int rep = 0; rep < 3; rep++) {
@@ -39,20 +48,24 @@ template <int NT> static int run(int ncols, int k, int max_iter)
         hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms1, e0, e1);
         a.Xout = dO2;
         hipEventRecord(e0);
-        sweep_consts_kernel<<<1, 256>>>(dG, KP, k, a.r0, a.r1, dK);
-        sweep_scd_wg_kernel<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
+        sweep_consts_kernel<<<1, 256>>>(dG, KP, k, a.r0, a.r1, dK, FASTV ? 1 : 0);
+        WGK<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
         hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms2, e0, e1);
     }
     CK(hipGetLastError());
     {
-        unsigned long long *dT, T[4];
-        CK(hipMalloc(&dT, 32)); CK(hipMemset(dT, 0, 32));
+        unsigned long long *dT, T[18];
+        CK(hipMalloc(&dT, 144)); CK(hipMemset(dT, 0, 144));
         SweepArgs b2 = a; b2.op = dT; b2.op_mode = 0; b2.Xout = dO2;
-        sweep_scd_wg_kernel<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(b2, dK);
-        CK(hipMemcpy(T, dT, 32, hipMemcpyDeviceToHost));
+        WGK<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(b2, dK);
+        CK(hipMemcpy(T, dT, 144, hipMemcpyDeviceToHost));
         const double steps = (double)max_iter * ((k + 3) / 4);
         printf("  per step (100 MHz ticks x 24 ~ cycles): chain wave work %.1f wait %.1f | update wave work %.1f wait %.1f  [raw counter units]\n",
                T[0] / steps, T[1] / steps, T[2] / steps, T[3] / steps);
+#ifdef SWEEP_WG_MARKS
+        printf("  chain marks :"); for (int i = 0; i < 7; i++) printf(" %.0f", T[4 + i] / steps); printf("\n");
+        printf("  update marks:"); for (int i = 0; i < 7; i++) printf(" %.0f", T[11 + i] / steps); printf("\n");
+#endif
         hipFree(dT);
     }
     std::vector<double> O1(X.size()), O2(X.size()), K(16 * SWEEP_WG_CONSTS);
