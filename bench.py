@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_, M_, K_ = 20000, 10000, 50
-INNER, INNER_TOL, METHOD = 50, 1e-9, 1
+INNER, INNER_TOL, METHOD = 50, float(os.environ.get("NNLM_BENCH_INNER_TOL", "1e-9")), 1  # (env: experiments only)
 SEED = 20250928
 
 
@@ -55,7 +55,8 @@ def pmc_traffic(kernel):
     (MI355X_MICROARCH.md, HBM section): a wide streaming read is tallied at half its bytes, so reads = 2 x FETCH_SIZE.
     bench.py cannot attach rocprofv3 to itself: (None, None) when no summary is committed."""
     import glob, re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_summary.txt")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_summary.txt")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v10 after r01_v9
     if not files:
         return None, None
     fetch = write = None
