@@ -458,3 +458,29 @@ def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, met
     assert np.array_equal(res[0][0][Wm], W0[Wm])
     assert sweeps == sw_ref
     assert abs(mse - mse_ref) < 1e-9 * mse_ref if pname == "f64" else abs(mse - mse_ref) < 1e-5 * mse_ref
+
+
+# ---- the restructured SCD sweep of the f32 mode (k_sweep_wgf.h): masks, columns that finish early, ragged shapes ------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 101, 9), (257, 1000, 17), (120, 49, 33), (400, 530, 50), (90, 97, 64)])
+@pytest.mark.parametrize("inner,itol", [(50, 1e-3), (7, 1e-9), (200, 1e-6)])
+def test_fast_sweep_with_masks_and_early_finishers(shape, inner, itol):
+    n, m, k = shape
+    rng = np.random.default_rng(7 * n + m + k + inner)
+    A = rng.random((n, m))
+    Wt = rng.random((k, n))
+    H0 = rng.random((k, m)) * (rng.random((k, m)) > 0.3)  # zeros that have to stay / leave zero
+    mask = rng.random((k, m)) < 0.15
+    mask[:, :: 11] = True  # whole columns masked: skipped (src/update_with_missing.cpp:33)
+    mask[:, 5] = False
+    H0[mask] = 0.0
+    reg = [0.02, 0.01, 0.03]
+    H_ref, it_ref = ref.update(H0.copy(), Wt, A, mask, reg, inner, itol, 1)
+    Hn, sweeps = hip_update(nnlm_amd.PREC_F32, H0.copy(), Wt, A, mask, reg, inner, itol, 1)
+    assert np.all(Hn[mask] == 0.0)
+    assert np.all(Hn >= 0.0)
+    assert relF(Hn, H_ref) < 1e-4
+    # integer sweep counts: identical decisions except for columns sitting on the tolerance
+    assert abs(sweeps - it_ref) <= max(2, it_ref // 200)
+    # fully masked columns are untouched, bit for bit
+    assert np.array_equal(Hn[:, ::11][:, 1:], H0[:, ::11][:, 1:])
