@@ -438,10 +438,12 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
     }
     __syncthreads(); // x image final
 
+    float xmax = 0.0f;
     for (int e = tid; e < SWEEP_WG_COLS * KP; e += SWEEP_WG_THREADS) {
         const int q = e / SWEEP_WG_COLS, c = e % SWEEP_WG_COLS, col = col_base + c;
         if (q < k && col < a.ncols) {
             const double xv = xl[c * XS + q];
+            xmax = fmaxf(xmax, fabsf((float)xv));
             a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
             if (a.op_mode == 1) {
                 if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
@@ -458,6 +460,35 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                 else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
             }
         }
+    }
+    if (a.maxbits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
+    }
+    if (a.gram_slabs) {
+        // Gram partial sums of this workgroup's columns (what gram_partial_kernel, k_gram.h, would compute after reading the
+        // factor back; rows of padded / out-of-range columns of the x image are zero): X X^T over the 48 columns with
+        // v_mfma_f64_16x16x4_f64, upper tiles dealt to the four wavefronts, same slab layout as gram_partial_kernel.
+        // ~1 us per workgroup.  The slabs are folded by gram_fold_kernel (k_gram.h) -- NOT here: a "last workgroup of a
+        // group adds them" step needs __threadfence(), and two of those per workgroup cost 65 us of the kernel's tail.
+        const int l15 = lane & 15, lg = lane >> 4;
+        double *slab = a.gram_slabs + (size_t)blockIdx.x * KP * KP;
+        int tix = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+            for (int tb = ta; tb < NT; tb++) {
+                if ((tix++ & 3) != wave) continue;
+                f64x4 acc = f64x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < SWEEP_WG_COLS / 4; s4++) {
+                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = acc[r];
+            }
     }
 #ifdef SWEEP_WG_TIMING
     if (a.op && blockIdx.x == 0 && lane == 0 && (wave == CW || wave == 1)) {

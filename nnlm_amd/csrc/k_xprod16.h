@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void absmax_f32_kernel(const float *__restrict
 // Y16 [KP][plen/64][2][64] from the fp64 master X [KP][ld]; exp_out = the exponent used (read by the cross product).
 // One thread per element; maxbits comes from absmax_f64_kernel (zeroed by the host before that pass).
 __global__ __launch_bounds__(256) void factor16_kernel(const double *__restrict__ X, int ld, int ncols, int k, int KP, int plen,
-                                                       unsigned *__restrict__ maxbits, int *__restrict__ exp_out, uint32_t *__restrict__ Y16)
+                                                       unsigned *__restrict__ maxbits, int *__restrict__ exp_out, uint32_t *__restrict__ Y16,
+                                                       unsigned *__restrict__ zero_word = nullptr)
 {
     const int e = split16_exponent(__uint_as_float(*maxbits));
     const float scale = ldexpf(1.0f, e);
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(256) void factor16_kernel(const double *__restrict_
         row[i & 63] = hi;
         row[64 + (i & 63)] = lo;
     }
-    if (idx == 0) *exp_out = e;
+    if (idx == 0) {
+        *exp_out = e;
+        if (zero_word) *zero_word = 0u; // the word the sweep of THIS half-step accumulates its max into
+    }
 }
 
 // A16 [cols][plen/64][2][64] from the resident fp32 A [cols][lda] (same column-major geometry, plen = lda)

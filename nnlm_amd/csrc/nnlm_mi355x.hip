@@ -101,7 +101,13 @@ struct nnlm_handle {
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
-    unsigned *maxbits = nullptr; // device [4]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter
+    unsigned *maxbits = nullptr; // device [8]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter,
+                                 // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_wgf.h)
+    // What the fast sweep leaves behind for the next half-step (dense one-GPU split-fp16 path): max|x| in maxbits[4 + sg_par] and
+    // sg_nslabs Gram partial sums (one per workgroup) in sg_slabs.  sg_which: the factor they describe (1 = H, 0 = W, -1 = none).
+    int sg_which = -1, sg_par = 0, sg_nslabs = 0;
+    bool sg_request = false;     // set by half_step for the sweep it is about to launch
+    double *sg_slabs = nullptr;
     int mb_par = 0;
     bool consts_ready = false;   // sweep_consts image already produced for this half-step (gram_reduce_consts_kernel)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
@@ -275,13 +281,13 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->maxbits, 4 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&h->maxbits, 8 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
     hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
     hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
-    hipMemsetAsync(h->maxbits, 0, 4 * sizeof(unsigned), h->stream);
+    hipMemsetAsync(h->maxbits, 0, 8 * sizeof(unsigned), h->stream);
     hipStreamSynchronize(h->stream);
     h->x16 = x16_enabled(precision);
     *out = h;
@@ -311,6 +317,9 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->H16c);
     h->Y16 = h->W16c = h->H16c = nullptr;
     hipFree(h->gslabs);
+    hipFree(h->sg_slabs);
+    h->sg_slabs = nullptr;
+    h->sg_which = -1;
     hipFree(h->red);
     hipFree(h->pack_send);
     hipFree(h->pack_all);
@@ -602,6 +611,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     h->wcur = 0;
     h->W64 = h->W64b[0];
     h->Wop = h->Wopb[0];
+    h->sg_which = -1;
     h->sw_active = 0;
     HIPCHK(h, hipMemset(h->sweeps, 0, 2 * sizeof(unsigned long long)));
     const int KP = h->KP, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
@@ -730,7 +740,7 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
 // scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
 // made the step SLOWER by 1 % -- the Gram kernels then overlap more of the (now HBM-bound) cross product.
 // mb: device word that already holds max|factor| (from gram_partial_kernel), or NULL: compute it here
-static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr)
+static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, unsigned *zero_word = nullptr)
 {
     const double *Ym = (which == 1) ? h->W64 : h->H64;
     const int ldm = (which == 1) ? h->npad : h->mpad; // leading dimension of the master = padded contraction length
@@ -741,7 +751,7 @@ static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr)
         absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, mb);
     }
     const size_t cnt = (size_t)h->KP * ldm;
-    factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, mb, h->scal_exp + 1, h->Y16);
+    factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, mb, h->scal_exp + 1, h->Y16, zero_word);
     if (which == 0 && h->fuse_err) { // the fused error block also needs H and W with kq contiguous (same exponent for H)
         factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, mb, nullptr, h->H16c);
         hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
@@ -1156,6 +1166,9 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
     HIPCHK(h, hipSetDevice(h->device));
+    const int sg_which = h->sg_which; // what the previous sweep left behind (any half-step rewrites a factor: reset first)
+    h->sg_which = -1;
+    h->sg_request = false;
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
     if (h->any_missing && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
     if (partial_only) phase = PH_A;
@@ -1177,6 +1190,35 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     static int one_stream_env = getenv("NNLM_ONE_STREAM") ? atoi(getenv("NNLM_ONE_STREAM")) : 1;
     h->consts_ready = false;
     if (one_stream_env && h->x16 && !h->sharded && !h->any_missing && method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
+        // The fast sweep kernel (k_sweep_wgf.h) leaves max|x| and the Gram partial sums of the factor it solved -- the fixed
+        // factor of the NEXT half-step -- behind, computed from its LDS image (+1 us per sweep): the three kernels in front of
+        // the cross product are then factor16 (5 us), gram_fold (sum of the workgroups' slabs) and sweep_consts, none of
+        // which needs a fence -- gram_partial (12 us) and the "last block" step of gram_reduce_consts (most of its 15 us:
+        // __threadfence() is a cross-XCD cache write-back here) are gone.  NNLM_SWEEP_GRAM=0: the Gram kernels read the factor back.
+        static int sweep_gram_env = getenv("NNLM_SWEEP_GRAM") ? atoi(getenv("NNLM_SWEEP_GRAM")) : 1;
+        const bool fastsw = sweep_fast(h) && sweep_gram_env;
+        if (fastsw && !h->sg_slabs) {
+            const int big = h->n > h->m ? h->n : h->m;
+            const int nwg = (big + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+            HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)nwg * h->KP * h->KP * 8));
+        }
+        unsigned *smax_w = fastsw ? h->maxbits + 4 + (h->sg_par ^ 1) : nullptr; // this half-step's sweep writes its max here
+        h->sg_request = fastsw;
+        if (fastsw && sg_which == (which == 1 ? 0 : 1)) {
+            {
+                ProfScope ps(h, P_GRAM, h->stream);
+                prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w);
+                gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+                sweep_consts_kernel<<<1, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], h->sweep_consts, 1);
+                h->consts_ready = true;
+            }
+            {
+                ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
+                launch_xprod16(h, which, p);
+            }
+            if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream));
+            return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase);
+        }
         unsigned *mb = h->maxbits + 1 + h->mb_par, *mb_next = h->maxbits + 1 + (h->mb_par ^ 1);
         h->mb_par ^= 1;
         const double *Ym = (which == 1) ? h->W64 : h->H64;
@@ -1191,7 +1233,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
             default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
             }
-            prepare_factor16(h, which, mb);
+            prepare_factor16(h, which, mb, smax_w);
             gram_reduce_consts_kernel<<<h->KP * h->KP / 64, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw, h->k, reg[0], reg[1], h->sweep_consts,
                                                                              h->maxbits + 3, mb_next, sweep_fast(h) ? 1 : 0);
             h->consts_ready = true;
@@ -1295,6 +1337,12 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         a.sweeps = h->sweeps + (speculative ? (h->sw_active ^ 1) : h->sw_active);
         a.col0 = 0;
         a.ocol0 = 0;
+        const bool sg = h->sg_request; // (only on the dense one-GPU split-fp16 path, where k_sweep_wgf.h runs)
+        h->sg_request = false;
+        if (sg) {
+            a.maxbits = h->maxbits + 4 + (h->sg_par ^ 1);
+            a.gram_slabs = h->sg_slabs;
+        }
         if (which == 1) {
             a.X = h->H64;
             a.Xout = h->H64;
@@ -1351,8 +1399,14 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             }
             a.Graw = h->Gcols;
             launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
-        } else if (a.ncols > a.col0)
+        } else if (a.ncols > a.col0) {
             launch_sweep(h, method, a);
+            if (sg) { // the next half-step finds max and Gram partial sums of this factor
+                h->sg_nslabs = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+                h->sg_par ^= 1;
+                h->sg_which = which;
+            }
+        }
         HIPCHK(h, hipGetLastError());
         if (h->sharded && phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
     }
@@ -1838,6 +1892,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         }
     }
     if (spec_pending) { // the stopping rule fired: drop the speculative half-step (W_i is untouched) and its sweep count
+        h->sg_which = -1;
         HIPCHK(h, hipMemsetAsync(h->sweeps + (h->sw_active ^ 1), 0, sizeof(unsigned long long), h->stream));
         spec_pending = false;
     }

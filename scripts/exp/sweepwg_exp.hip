@@ -37,6 +37,13 @@ template <int NT> static int run(int ncols, int k, int max_iter)
     SweepArgs a{};
     a.X = dX; a.ldx = ld; a.ldo = ld; a.ocol0 = 0; a.col0 = 0; a.Graw = dG; a.KPg = KP; a.Cx = dC; a.slab_stride = (size_t)KP * ld; a.nslabs = 1; a.ldc = ld;
     a.ncols = ncols; a.k = k; a.r0 = 0.02; a.r1 = 0.01; a.r2 = 0.03; a.mask = nullptr; a.max_iter = max_iter; a.rel_tol = getenv("REL_TOL") ? atof(getenv("REL_TOL")) : 1e-9; a.op = nullptr; a.op_mode = 0; a.sweeps = dS;
+#if FASTV
+    if (getenv("GRAM")) { // the epilogue that leaves max|x| and Gram partial sums behind
+        const int nwg = (ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+        CK(hipMalloc(&a.gram_slabs, (size_t)nwg * KP * KP * 8));
+        CK(hipMalloc(&a.maxbits, 4)); CK(hipMemset(a.maxbits, 0, 4));
+    }
+#endif
     const int lds = FASTV ? sweep_wgf_lds_bytes(NT) : sweep_wg_lds_bytes(NT);
     CK(hipFuncSetAttribute((const void *)WGK<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -374,7 +374,8 @@ def test_virtual_rank_partials_sum_to_the_unsharded_buffer(pname, prec, tol, wor
 def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
     """The multi-GPU code path end to end on one GPU: a real RCCL communicator of size 1 makes the handle fold its slabs,
     call ncclAllReduce, sweep its column slab into the packed buffer, call ncclAllGather and unpack.  With one rank every
-    collective is the identity, so the result must be bit-identical to the plain path (same reduction orders)."""
+    collective is the identity, so the result must be bit-identical to the plain path in the strict mode (same reduction
+    orders) and equal to rounding in the f32 mode."""
     rng = np.random.default_rng(77)
     n, m, k = 300, 200, 9
     A = rng.random((n, m))
@@ -396,8 +397,16 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
             W, H = h.get_factors()
             out.append((W, H, sweeps, mse, kl, pen, r))
     a, b = out
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
-    assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
+    if pname == "f32":
+        # the plain F32 path takes the Gram partial sums of a solved factor from the sweep kernel's LDS image (one slab per
+        # workgroup of 48 columns, k_sweep_wgf.h), the sharded path from gram_partial_kernel (256 columns per slab): the same
+        # products in another order of addition -- 1e-15 differences in the fp64 Gram (one half-step: 2e-15 in the factor),
+        # which eight half-steps of coordinate descent amplify to ~1e-7 (scripts/gpu_sg_ab.py); the mode's parity bound is 1e-4
+        assert relF(a[0], b[0]) < 1e-5 and relF(a[1], b[1]) < 1e-5 and abs(a[2] - b[2]) <= 2
+        assert np.isclose(a[3], b[3], rtol=1e-6) and np.isclose(a[4], b[4], rtol=1e-6) and np.allclose(a[5], b[5], rtol=1e-6)
+    else:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
     for key in ("mse_error", "mkl_error", "target_error", "average_epoch"):
         if pname == "f32" and key != "average_epoch":
             # the plain F32 path evaluates the error sums inside the speculative cross product (xprod16_err_kernel, A rebuilt
