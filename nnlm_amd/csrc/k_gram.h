@@ -91,11 +91,11 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restr
 // G = sum of MANY slabs (one per workgroup of the fast sweep kernel, k_sweep_wgf.h: hundreds), no fences, fixed order:
 // a block owns 64 consecutive entries, its 16 wavefronts add every 16th slab (coalesced 512-byte reads), LDS folds the
 // 16 partial sums in index order.  Launch with KP*KP/64 blocks of 1024 threads.  Lower tiles are written as mirrors.
-__global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G)
+__device__ static inline void gram_fold_body(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G, int blk)
 {
     __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
+    const int e = blk * 64 + lane;
     const int a = e / KP, b = e % KP;
     const bool upper = (a >> 4) <= (b >> 4); // the slabs hold upper tiles only (lanes of lower tiles idle)
     double s = 0.0;
@@ -112,6 +112,10 @@ __global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restric
         G[e] = t;
         if ((a >> 4) < (b >> 4)) G[(size_t)b * KP + a] = t;
     }
+}
+__global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G)
+{
+    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
 }
 
 // G[a][b] = sum over slabs (fixed order); entries of lower tiles are read from the mirrored upper tile.

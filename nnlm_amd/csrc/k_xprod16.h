@@ -19,6 +19,7 @@
 #pragma once
 #include "common.h"
 #include "k_xprod.h"
+#include "k_gram.h"
 
 typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
 #define XPROD16_LO_SCALE 2048.0f // 2^11
@@ -184,6 +185,36 @@ __global__ __launch_bounds__(256) void factor16_kernel(const double *__restrict_
     if (idx == 0) {
         *exp_out = e;
         if (zero_word) *zero_word = 0u; // the word the sweep of THIS half-step accumulates its max into
+    }
+}
+
+// factor16_kernel and gram_fold_kernel (k_gram.h) in ONE launch of 1024-thread blocks -- the two are independent and each is
+// as long as a launch is (4.5 us): blocks [0, KP*KP/64) fold the Gram slabs, the rest convert 1024 entries of the factor each.
+__global__ __launch_bounds__(1024) void factor16_fold_kernel(const double *__restrict__ X, int ld, int ncols, int k, int KP, int plen,
+                                                             unsigned *__restrict__ maxbits, int *__restrict__ exp_out, uint32_t *__restrict__ Y16,
+                                                             unsigned *__restrict__ zero_word, const double *__restrict__ slabs, int nslabs,
+                                                             double *__restrict__ G)
+{
+    const int nfold = KP * KP / 64;
+    if ((int)blockIdx.x < nfold) {
+        gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
+        return;
+    }
+    const int e = split16_exponent(__uint_as_float(*maxbits));
+    const float scale = ldexpf(1.0f, e);
+    const size_t idx = (size_t)(blockIdx.x - nfold) * 1024 + threadIdx.x; // over KP * plen
+    if (idx < (size_t)KP * plen) {
+        const int q = (int)(idx / plen), i = (int)(idx % plen);
+        const float v = (q < k && i < ncols) ? (float)X[(size_t)q * ld + i] : 0.0f;
+        _Float16 hi, lo;
+        split16(v, scale, hi, lo);
+        _Float16 *row = (_Float16 *)(Y16 + (size_t)q * plen + (size_t)(i >> 6) * 64);
+        row[i & 63] = hi;
+        row[64 + (i & 63)] = lo;
+    }
+    if (idx == 0) {
+        *exp_out = e;
+        if (zero_word) *zero_word = 0u;
     }
 }
 

@@ -1207,8 +1207,16 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (fastsw && sg_which == (which == 1 ? 0 : 1)) {
             {
                 ProfScope ps(h, P_GRAM, h->stream);
-                prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w);
-                gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+                if (h->fuse_err) { // (the fused error block needs more split copies: the general routine)
+                    prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w);
+                    gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+                } else {
+                    const double *Ym = (which == 1) ? h->W64 : h->H64;
+                    const int ldm = (which == 1) ? h->npad : h->mpad, lim = (which == 1) ? h->n : h->m;
+                    const size_t cnt = (size_t)h->KP * ldm;
+                    factor16_fold_kernel<<<(unsigned)(h->KP * h->KP / 64 + (cnt + 1023) / 1024), 1024, 0, h->stream>>>(
+                        Ym, ldm, lim, h->k, h->KP, ldm, h->maxbits + 4 + h->sg_par, h->scal_exp + 1, h->Y16, smax_w, h->sg_slabs, h->sg_nslabs, h->Graw);
+                }
                 sweep_consts_kernel<<<1, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], h->sweep_consts, 1);
                 h->consts_ready = true;
             }
