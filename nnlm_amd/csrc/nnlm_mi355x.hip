@@ -106,6 +106,8 @@ struct nnlm_handle {
     // What the fast sweep leaves behind for the next half-step (dense one-GPU split-fp16 path): max|x| in maxbits[4 + sg_par] and
     // sg_nslabs Gram partial sums (one per workgroup) in sg_slabs.  sg_which: the factor they describe (1 = H, 0 = W, -1 = none).
     int sg_which = -1, sg_par = 0, sg_nslabs = 0;
+    int sg_other = -1;           // the factor whose max the OTHER word (maxbits[4 + (sg_par ^ 1)]) still holds, or -1
+    int sg_prev = -1;            // sg_which as the current half-step found it (becomes sg_other after its sweep)
     bool sg_request = false;     // set by half_step for the sweep it is about to launch
     double *sg_slabs = nullptr;
     int mb_par = 0;
@@ -319,7 +321,7 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->gslabs);
     hipFree(h->sg_slabs);
     h->sg_slabs = nullptr;
-    h->sg_which = -1;
+    h->sg_which = h->sg_other = -1;
     hipFree(h->red);
     hipFree(h->pack_send);
     hipFree(h->pack_all);
@@ -611,7 +613,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     h->wcur = 0;
     h->W64 = h->W64b[0];
     h->Wop = h->Wopb[0];
-    h->sg_which = -1;
+    h->sg_which = h->sg_other = -1;
     h->sw_active = 0;
     HIPCHK(h, hipMemset(h->sweeps, 0, 2 * sizeof(unsigned long long)));
     const int KP = h->KP, n = h->n, m = h->m, npad = h->npad, mpad = h->mpad;
@@ -740,7 +742,9 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
 // scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
 // made the step SLOWER by 1 % -- the Gram kernels then overlap more of the (now HBM-bound) cross product.
 // mb: device word that already holds max|factor| (from gram_partial_kernel), or NULL: compute it here
-static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, unsigned *zero_word = nullptr)
+// w_max_in_zero_word: zero_word (about to be cleared for this half-step's sweep) still holds max|W| of the current W, left by
+// the sweep that solved it -- the fused error block's split copy of W then needs no absmax pass (24 us) of its own.
+static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, unsigned *zero_word = nullptr, bool w_max_in_zero_word = false)
 {
     const double *Ym = (which == 1) ? h->W64 : h->H64;
     const int ldm = (which == 1) ? h->npad : h->mpad; // leading dimension of the master = padded contraction length
@@ -751,12 +755,17 @@ static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, 
         absmax_f64_kernel<<<(plen_true + 255) / 256, 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, mb);
     }
     const size_t cnt = (size_t)h->KP * ldm;
+    const bool fuse = which == 0 && h->fuse_err; // the fused error block also needs H and W with kq contiguous (same exponent for H)
+    if (fuse && w_max_in_zero_word && zero_word) // (before factor16_kernel clears that word)
+        factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, zero_word, h->scal_exp + 2, h->W16c);
     factor16_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(Ym, ldm, plen_true, h->k, h->KP, ldm, mb, h->scal_exp + 1, h->Y16, zero_word);
-    if (which == 0 && h->fuse_err) { // the fused error block also needs H and W with kq contiguous (same exponent for H)
+    if (fuse) {
         factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, mb, nullptr, h->H16c);
-        hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
-        absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits);
-        factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits, h->scal_exp + 2, h->W16c);
+        if (!(w_max_in_zero_word && zero_word)) {
+            hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
+            absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits);
+            factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits, h->scal_exp + 2, h->W16c);
+        }
     }
 }
 template <int NKQ>
@@ -1167,7 +1176,9 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
     HIPCHK(h, hipSetDevice(h->device));
     const int sg_which = h->sg_which; // what the previous sweep left behind (any half-step rewrites a factor: reset first)
-    h->sg_which = -1;
+    const int sg_other = h->sg_other;
+    h->sg_prev = sg_which;
+    h->sg_which = h->sg_other = -1;
     h->sg_request = false;
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
     if (h->any_missing && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
@@ -1208,7 +1219,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             {
                 ProfScope ps(h, P_GRAM, h->stream);
                 if (h->fuse_err) { // (the fused error block needs more split copies: the general routine)
-                    prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w);
+                    prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w, which == 0 && sg_other == 0);
                     gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
                 } else {
                     const double *Ym = (which == 1) ? h->W64 : h->H64;
@@ -1413,6 +1424,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                 h->sg_nslabs = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
                 h->sg_par ^= 1;
                 h->sg_which = which;
+                h->sg_other = h->sg_prev; // the word this sweep did not touch
             }
         }
         HIPCHK(h, hipGetLastError());
@@ -1900,7 +1912,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         }
     }
     if (spec_pending) { // the stopping rule fired: drop the speculative half-step (W_i is untouched) and its sweep count
-        h->sg_which = -1;
+        h->sg_which = h->sg_other = -1;
         HIPCHK(h, hipMemsetAsync(h->sweeps + (h->sw_active ^ 1), 0, sizeof(unsigned long long), h->stream));
         spec_pending = false;
     }
