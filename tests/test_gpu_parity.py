@@ -472,7 +472,7 @@ def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, met
 # ---- the restructured SCD sweep of the f32 mode (k_sweep_wgf.h): masks, columns that finish early, ragged shapes ------
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(300, 101, 9), (257, 1000, 17), (120, 49, 33), (400, 530, 50), (90, 97, 64)])
-@pytest.mark.parametrize("inner,itol", [(50, 1e-3), (7, 1e-9), (200, 1e-6)])
+@pytest.mark.parametrize("inner,itol", [(50, 1e-3), (7, 1e-9), (200, 1e-6), (0, 1e-9), (1, -1.0)])
 def test_fast_sweep_with_masks_and_early_finishers(shape, inner, itol):
     n, m, k = shape
     rng = np.random.default_rng(7 * n + m + k + inner)
