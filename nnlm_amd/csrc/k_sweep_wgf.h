@@ -55,7 +55,6 @@ __host__ __device__ static inline int sweep_wgf_lds_bytes(int NT) { return sweep
 template <int NT, bool HAS_MASK>
 __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const SweepArgs a, const double *__restrict__ consts_g)
 {
-    constexpr bool FAST = true;
     constexpr int KP = 16 * NT, NB = 4 * NT;
     constexpr int XS = KP + 2; // row stride of the x image: 16-byte aligned rows, b128 reads of 16 lanes hit 16 distinct slots
     constexpr int CW = 0;      // the chain wave
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
     double(*dbuf)[SWEEP_WG_LCOLS * 4] = (double(*)[SWEEP_WG_LCOLS * 4])(xl + SWEEP_WG_LCOLS * XS); // [parity][column][g] deltas of a block
     double(*fbuf)[SWEEP_WG_LCOLS * 4] = dbuf + 2;                // [parity][column][s] far gradient of a block
     int *ctrl = (int *)(fbuf + 2);                               // [2]  "another sweep follows", by parity of its last step
-    unsigned long long *actw = (unsigned long long *)(ctrl + 2); // [2]  FAST: ballot of the columns still being swept
+    unsigned long long *actw = (unsigned long long *)(ctrl + 2); // [2]  ballot of the columns still being swept
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     const int nbk = (k + 3) / 4;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         const int b = e / (NT * 64), rem = e % (NT * 64), t = rem / 64, g = (rem % 64) / 16, l = rem % 16;
         const int c = 4 * ((l >> 2) * NT + t) + (l & 3), kc = 4 * b + g;
         double gv = (c < k && kc < k) ? edited(c, kc) : 0.0;
-        if (FAST && c < k) gv *= consts_g[(c >> 2) * SWEEP_WG_CONSTS + (c & 3)]; // row c / G[c][c]
+        if (c < k) gv *= consts_g[(c >> 2) * SWEEP_WG_CONSTS + (c & 3)]; // row c / G[c][c]
         Gz[e] = gv;
     }
     for (int e = tid; e < SWEEP_WG_LCOLS * KP; e += SWEEP_WG_THREADS) {
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
             if (e < NB && q < k)
                 for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)q * a.ldc + cc];
             mu[e] = (e < NB && q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) : 0.0;
-            if (FAST && e < NB && q < k) mu[e] *= consts_g[(q >> 2) * SWEEP_WG_CONSTS + (q & 3)];
+            if (e < NB && q < k) mu[e] *= consts_g[(q >> 2) * SWEEP_WG_CONSTS + (q & 3)];
         }
         const double *gzl = Gz + lane; // + (b*NT + t)*64
 #define SWEEP_WG_RANK4(bidx, coef)                                                                                       \
@@ -147,11 +146,11 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         // stands between the arrival of d_{b-1} and `far`.
         int par = 0, pb = nbk - 1; // step parity; block whose deltas arrive in this step (all zero in step 0)
         bool go = true;
-        // FAST: x is kept by the update waves, x[block pb] += d, one LDS read-modify-write per lane and step (the chain wave
+        // x is kept by the update waves, x[block pb] += d, one LDS read-modify-write per lane and step (the chain wave
         // only reads x).  Columns that are done must keep their x: the ballot of live columns of the sweep the deltas
         // belong to (block pb = the last block <=> the previous sweep) comes from the chain wave with `ctrl`.
         // mine_cur: this lane's column was live in the sweep the arriving deltas belong to (switches after step 0)
-        bool mine_next = FAST ? ((actw[0] >> cl) & 1ull) != 0 : false, mine_cur = mine_next; // (written before the barrier above)
+        bool mine_next = ((actw[0] >> cl) & 1ull) != 0, mine_cur = mine_next; // (written before the barrier above)
         double *xcell = xl + cl * XS + lg; // + 4 * pb
         // A operands, fetched before the barrier of the previous step: gzl_[t] = G[tile t, block of d_prev]; gzu = G[tile of the
         // next block, block pb] for the urgent product.  When the next block is block 0 (tile 0) the urgent product is
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     double &d = dq[ALT ? (t0 & 1) : 0], &d_prev = dq[ALT ? ((t0 & 1) ^ 1) : 1];
                     double xold = 0.0;
                     asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"((unsigned)(size_t)&dbuf[par ^ 1][cl * 4 + lg]));
-                    if (FAST) asm volatile("ds_read_b64 %0, %1" : "=v"(xold) : "v"((unsigned)(size_t)&xcell[4 * pb]));
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(xold) : "v"((unsigned)(size_t)&xcell[4 * pb]));
                     const bool wrap = !(b + 1 < nbk); // the next block is block 0: tile 0, register 0
                     const int tn = (t0 + 1) % NT;
                     const int rn = (t0 == NT - 1) ? r0 + 1 : r0;
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     for (int t2 = 0; t2 < NT; t2++) gzl_[t2] = gzl[(pb * NT + t2) * 64];
                     if (LATE) gzlate[(t0 & 1) ^ 1] = gzl[(pb * NT + ((wrap ? 0 : t0 + 1) + NT - 1) % NT) * 64];
                     // x before the urgent product (the fp64 MFMA holds up every VALU instruction behind it)
-                    if (FAST && mine_cur) xcell[4 * pb] = xold + d;
+                    if (mine_cur) xcell[4 * pb] = xold + d;
                     SWG_MARK(3)
                     SWG_TILE_FMA(tn, gzu, d)
                     if (tn != 0 && wrap) SWG_TILE_FMA(0, gzw, d)
@@ -254,14 +253,14 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     pb = b;
                     if (b == nbk - 1) {
                         go = ctrl[par] != 0;
-                        if (FAST) mine_next = ((actw[par] >> cl) & 1ull) != 0;
+                        mine_next = ((actw[par] >> cl) & 1ull) != 0;
                     }
-                    if (FAST && b == 0) mine_cur = mine_next;
+                    if (b == 0) mine_cur = mine_next;
                     par ^= 1;
                 }
             }
         }
-        if (FAST && mine_cur) xcell[4 * pb] += dbuf[par ^ 1][cl * 4 + lg]; // deltas of the very last step
+        if (mine_cur) xcell[4 * pb] += dbuf[par ^ 1][cl * 4 + lg]; // deltas of the very last step
 #undef SWG_TILE_FMA
 #undef SWEEP_WG_RANK4
     } else {
@@ -280,14 +279,10 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         bool go = a.max_iter > 0 && __any(act);
         // constants of a block: fetched through the scalar cache one step AHEAD (before the barrier of the previous step)
         struct Consts {
-            double rg[4], gd[4], gl[6];
+            double gl[6]; // scaled G[4b+s2][4b+s], s2 > s
         };
         auto load_chain = [&](int b, Consts &c) {
             const auto *cb = cdat + b * SWEEP_WG_CONSTS;
-            if (!FAST) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) c.rg[i] = cb[i], c.gd[i] = cb[4 + i];
-            }
 #pragma unroll
             for (int i = 0; i < 6; i++) c.gl[i] = cb[8 + i];
         };
@@ -300,7 +295,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         double xdummy = 0.5;
         (void)xdummy;
         f64x2 x01 = *(const f64x2 *)&xrow[0], x23 = *(const f64x2 *)&xrow[2]; // x of the next block
-        if (FAST) {
+        {
             const unsigned long long bal = __ballot(act);
             if (lane == 0) actw[0] = bal;
         }
@@ -343,34 +338,20 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                 SWG_EXTRA(SWEEP_WG_XB, xdummy)
                 const double xs[4] = {x01[0], x01[1], x23[0], x23[1]};
                 const double gl[4][4] = {{0, 0, 0, 0}, {cc.gl[0], 0, 0, 0}, {cc.gl[1], cc.gl[2], 0, 0}, {cc.gl[3], cc.gl[4], cc.gl[5], 0}};
-                double xn[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     if (SWEEP_WG_ABL & 8) {
                         dd[s] = act ? m[s] * 1e-30 : 0.0;
-                        xn[s] = xs[s];
                         continue;
                     }
                     // Padded coordinates (q >= k) are inert: x = mu = 0, G = identity.
-                    if (FAST) {
-                        // Columns that are done (act == false) keep being computed -- their lanes cost nothing -- but the
-                        // update waves do not store their x, so they stay exactly as the reference leaves them; their
-                        // deltas only reach their own columns of the update waves.
-                        // m = mu / G[q][q]: delta = max(x - m, 0) - x = max(-x, -m); written as the instruction because
-                        // fmax() makes the compiler canonicalise x first and negate the result afterwards (3 instructions)
-                        asm("v_max_f64 %0, -%1, -%2" : "=v"(dd[s]) : "v"(xs[s]), "v"(m[s]));
-                        xn[s] = 0.0; // x + delta: stored by the update waves
-                    } else {
-                        const double q0 = m[s] * cc.rg[s];
-                        const double rr = __builtin_fma(-q0, cc.gd[s], m[s]);
-                        const double quo = __builtin_fma(rr, cc.rg[s], q0); // = mu / G[q][q], correctly rounded
-                        const double tmp = fmax(xs[s] - quo, 0.0);
-                        bool upd = act;
-                        if (HAS_MASK) upd = upd && !((mword >> (4 * b + s)) & 1ull);
-                        dd[s] = upd ? tmp - xs[s] : 0.0;
-                        xn[s] = upd ? tmp : xs[s];
-                    }
-                    if (FAST && HAS_MASK && ((mword >> (4 * b + s)) & 1ull)) dd[s] = 0.0;
+                    // Columns that are done (act == false) keep being computed -- their lanes cost nothing -- but the
+                    // update waves do not store their x, so they stay exactly as the reference leaves them; their
+                    // deltas only reach their own columns of the update waves.
+                    // m = mu / G[q][q]: delta = max(x - m, 0) - x = max(-x, -m); written as the instruction because
+                    // fmax() makes the compiler canonicalise x first and negate the result afterwards (3 instructions)
+                    asm("v_max_f64 %0, -%1, -%2" : "=v"(dd[s]) : "v"(xs[s]), "v"(m[s]));
+                    if (HAS_MASK && ((mword >> (4 * b + s)) & 1ull)) dd[s] = 0.0;
 #pragma unroll
                     for (int s2 = s + 1; s2 < 4; s2++) m[s2] = __builtin_fma(dd[s], gl[s2][s], m[s2]);
                 }
@@ -381,10 +362,6 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                 if (!(SWEEP_WG_ABL & 2)) {
                     *(f64x2 *)&dbuf[par][lane * 4] = f64x2{dd[0], dd[1]};
                     *(f64x2 *)&dbuf[par][lane * 4 + 2] = f64x2{dd[2], dd[3]};
-                    if (!FAST) {
-                        *(f64x2 *)&xrow[4 * b] = f64x2{xn[0], xn[1]};
-                        *(f64x2 *)&xrow[4 * b + 2] = f64x2{xn[2], xn[3]};
-                    }
                 }
                 // rel-change tests (src/base_algorithms.cpp:29-32), division-free.  Only "did ANY coordinate of the sweep move
                 // by more than rel_tol" matters, so once every column of the wave has its flag the tests of the remaining
@@ -392,11 +369,8 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                 SWG_MARK(4)
                 if (tests_on) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        if (FAST) // 2|d| > tol (x + d + x + eps), three instructions: |d| > (tol/2)(2x + d) + tol eps/2
-                            flag |= fabs(dd[s]) > __builtin_fma(tolh, __builtin_fma(2.0, xs[s], dd[s]), tolhe);
-                        else flag |= (2 * fabs(dd[s])) > tol * (xn[s] + xs[s] + NNLM_TINY); // (|=: no short-circuit branches)
-                    }
+                    for (int s = 0; s < 4; s++) // 2|d| > tol (x + d + x + eps) in three instructions: |d| > (tol/2)(2x + d) + tol eps/2
+                        flag |= fabs(dd[s]) > __builtin_fma(tolh, __builtin_fma(2.0, xs[s], dd[s]), tolhe); // (|=: no short-circuit branches)
                     tests_on = !__all(flag | !act);
                 }
                 const int nb = (b + 1 < nbk) ? b + 1 : 0;
@@ -408,7 +382,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     t++;
                     go = t < a.max_iter && __any(act);
                     if (lane == 0) ctrl[par] = go ? 1 : 0;
-                    if (FAST) {
+                    {
                         const unsigned long long bal = __ballot(act);
                         if (lane == 0) actw[par] = bal;
                     }
