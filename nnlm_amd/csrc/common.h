@@ -58,6 +58,11 @@ __device__ static inline long long wave_sum_ll(long long v)
     return v;
 }
 
+#define SWEEP_WG_CONSTS 40 // doubles per block in the constants image of the SCD sweep (k_sweep_wg.h, k_sweep_wgf.h)
+// First coordinate of the "tail block" of k_sweep_wgf.h -- k = 16 j + 1 or + 2, j >= 1: the one or two coordinates beyond a
+// multiple of 16 are carried by the chain wave and the update waves hold 16 j instead of 16 (j + 1) -- or -1.
+__host__ __device__ static inline int sweep_tail_coord(int k) { return (k > 16 && (k % 16 == 1 || k % 16 == 2)) ? (k / 16) * 16 : -1; }
+
 // One entry of the constants image the chain wave of sweep_scd_wg_kernel reads (layout: k_sweep_wg.h); shared by
 // sweep_consts_kernel and gram_reduce_consts_kernel.
 // FAST (fp32-operand mode): every row of G is divided by its diagonal, so the update waves carry nu = mu / G[q][q] and
@@ -74,11 +79,16 @@ template <class F> __device__ static inline double sweep_wg_const(F edited, int 
         const double v = edited(r, 4 * b + s[i - 8]);
         return fast ? v * (1.0 / edited(r, r)) : v;
     }
-    if (i >= 16) {
+    if (i >= 16 && i < 32) {
         const int ss = (i - 16) / 4, g = (i - 16) % 4, r = 4 * nb + ss;
         if (!(r < k && 4 * b + g < k)) return 0.0;
         const double v = edited(r, 4 * b + g);
         return fast ? v * (1.0 / edited(r, r)) : v;
+    }
+    if (i >= 32 && fast) { // [32..39]: scaled rows of the two tail coordinates, columns of block b (k_sweep_wgf.h, TAIL)
+        const int tc = sweep_tail_coord(k), r = tc + (i - 32) / 4, kc = 4 * b + (i - 32) % 4;
+        if (tc < 0 || !(r < k && kc < k)) return 0.0;
+        return edited(r, kc) * (1.0 / edited(r, r));
     }
     return 0.0;
 }

@@ -215,5 +215,5 @@ __global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *_
         if (c == kc) v += NNLM_TINY;
         return v;
     };
-    for (int t = threadIdx.x; t < nbk * 32; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / 32, t % 32, fast);
+    for (int t = threadIdx.x; t < nbk * SWEEP_WG_CONSTS; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / SWEEP_WG_CONSTS, t % SWEEP_WG_CONSTS, fast);
 }

@@ -28,7 +28,6 @@
 #define SWEEP_WG_THREADS 256 // 4 wavefronts = one per SIMD: the chain wave + 3 update waves
 #define SWEEP_WG_COLS 48     // columns per workgroup (16 per update wave; lanes 48..63 of the chain wave idle)
 #define SWEEP_WG_LCOLS 64    // rows of the LDS images (one per chain-wave lane)
-#define SWEEP_WG_CONSTS 32 // doubles per block in the constants image
 // SWEEP_WG_TIMING (scripts/exp/sweepwg_exp.hip only): cycles spent working / waiting at the step barrier, per role
 #ifndef SWEEP_WG_ABL
 #define SWEEP_WG_ABL 0 // ablation bits (scripts/exp/sweepwg_exp.hip only): 1 no constant reloads, 2 no LDS writes, 4 no near, 8 no chain

@@ -52,10 +52,15 @@
 #endif
 __host__ __device__ static inline int sweep_wgf_lds_bytes(int NT) { return sweep_wg_lds_bytes(NT) + 16; } // + the ballot words
 
-template <int NT, bool HAS_MASK>
+// TAIL (k = 16 (NT - 1) + 1 or + 2): the one or two coordinates beyond a multiple of 16 form a block of their own that no
+// update wave holds.  Their gradients live in two registers of the chain wave, which brings them up to date with every
+// block's deltas itself (8 FMAs per step, always current: no far / near for that block), and the update waves carry
+// NTU = NT - 1 tiles -- 3 instead of 4 MFMAs per step at k = 50, on the role that bounds the step.
+template <int NT, bool HAS_MASK, bool TAIL = false>
 __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const SweepArgs a, const double *__restrict__ consts_g)
 {
     constexpr int KP = 16 * NT, NB = 4 * NT;
+    constexpr int NTU = TAIL ? NT - 1 : NT; // tiles of an update wave
     constexpr int XS = KP + 2; // row stride of the x image: 16-byte aligned rows, b128 reads of 16 lanes hit 16 distinct slots
     constexpr int CW = 0;      // the chain wave
     // Gz[b][t][g][l] = edited G[coord(t, l)][4b + g];  coordinate of (tile t, accumulator row M) = 4*((M/4)*NT + t) + M%4
@@ -78,9 +83,9 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         if (c == kc) g += NNLM_TINY;
         return g;
     };
-    for (int e = tid; e < NB * NT * 64; e += SWEEP_WG_THREADS) {
-        const int b = e / (NT * 64), rem = e % (NT * 64), t = rem / 64, g = (rem % 64) / 16, l = rem % 16;
-        const int c = 4 * ((l >> 2) * NT + t) + (l & 3), kc = 4 * b + g;
+    for (int e = tid; e < NB * NTU * 64; e += SWEEP_WG_THREADS) {
+        const int b = e / (NTU * 64), rem = e % (NTU * 64), t = rem / 64, g = (rem % 64) / 16, l = rem % 16;
+        const int c = 4 * ((l >> 2) * NTU + t) + (l & 3), kc = 4 * b + g;
         double gv = (c < k && kc < k) ? edited(c, kc) : 0.0;
         if (c < k) gv *= consts_g[(c >> 2) * SWEEP_WG_CONSTS + (c & 3)]; // row c / G[c][c]
         Gz[e] = gv;
@@ -111,20 +116,20 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         f64x16 mu;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const int b = (e & 3) * NT + (e >> 2); // meaningful for e < 4*NT
+            const int b = (e & 3) * NTU + (e >> 2); // meaningful for e < 4*NTU
             const int q = 4 * b + lg;
             double cv = 0.0;
-            if (e < NB && q < k)
+            if (e < 4 * NTU && q < k)
                 for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)q * a.ldc + cc];
-            mu[e] = (e < NB && q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) : 0.0;
-            if (e < NB && q < k) mu[e] *= consts_g[(q >> 2) * SWEEP_WG_CONSTS + (q & 3)];
+            mu[e] = (e < 4 * NTU && q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) : 0.0;
+            if (e < 4 * NTU && q < k) mu[e] *= consts_g[(q >> 2) * SWEEP_WG_CONSTS + (q & 3)];
         }
         const double *gzl = Gz + lane; // + (b*NT + t)*64
 #define SWEEP_WG_RANK4(bidx, coef)                                                                                       \
-    _Pragma("unroll") for (int t2 = 0; t2 < NT; t2++)                                                                   \
+    _Pragma("unroll") for (int t2 = 0; t2 < NTU; t2++)                                                                  \
     {                                                                                                                   \
         f64x4 tile = f64x4{mu[4 * t2], mu[4 * t2 + 1], mu[4 * t2 + 2], mu[4 * t2 + 3]};                                  \
-        tile = __builtin_amdgcn_mfma_f64_16x16x4f64(gzl[((bidx) * NT + t2) * 64], (coef), tile, 0, 0, 0);                 \
+        tile = __builtin_amdgcn_mfma_f64_16x16x4f64(gzl[((bidx) * NTU + t2) * 64], (coef), tile, 0, 0, 0);                \
         mu[4 * t2] = tile[0];                                                                                           \
         mu[4 * t2 + 1] = tile[1];                                                                                       \
         mu[4 * t2 + 2] = tile[2];                                                                                       \
@@ -156,21 +161,21 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         // next block, block pb] for the urgent product.  When the next block is block 0 (tile 0) the urgent product is
         // issued on the static tile (t0 + 1) % NT with a ZERO operand and on tile 0 with the real one (gzw) -- a uniform
         // branch around an accumulator update makes the register allocator copy whole accumulators.
-        double gzl_[NT], gzu = 0.0, gzw = 0.0; // (first step: all deltas are zero)
+        double gzl_[NTU], gzu = 0.0, gzw = 0.0; // (first step: all deltas are zero)
         // deltas of this step and of the previous one in two registers that swap roles from step to step (static for even
         // NT): with `d_prev = d` the compiler gives both one register and the load of d has to wait for the lazy products
-        constexpr bool ALT = (NT % 2) == 0;
+        constexpr bool ALT = (NTU % 2) == 0 && !TAIL;
         double dq[2] = {0.0, 0.0};
         // NT = 4: the third lazy product is issued LATE, behind the store of `far` (it runs while that store drains); its
         // operand has a register of its own (two, swapping like dq: the next one is requested before this one is used)
         #ifdef SWEEP_WG_NOLATE
         constexpr bool LATE = false;
 #else
-        constexpr bool LATE = NT == 4;
+        constexpr bool LATE = NTU == 4;
 #endif
         double gzlate[2] = {0.0, 0.0};
 #pragma unroll
-        for (int t2 = 0; t2 < NT; t2++) gzl_[t2] = 0.0;
+        for (int t2 = 0; t2 < NTU; t2++) gzl_[t2] = 0.0;
 #define SWG_TILE_FMA(t2, A, B)                                                                                          \
     if (!(SWEEP_WG_ABL & 16)) {                                                                                                                   \
         f64x4 tile = f64x4{mu[4 * (t2)], mu[4 * (t2) + 1], mu[4 * (t2) + 2], mu[4 * (t2) + 3]};                          \
@@ -184,9 +189,9 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0++) { // fully unrolled: every accumulator element a step touches is a static register
 #pragma unroll
-                for (int t0 = 0; t0 < NT; t0++) {
-                    const int b = r0 * NT + t0; // consecutive blocks, consecutive tiles
-                    if (b >= nbk) continue;     // wave-uniform
+                for (int t0 = 0; t0 < NTU; t0++) {
+                    const int b = r0 * NTU + t0; // consecutive blocks, consecutive tiles
+                    if (b >= (TAIL ? 4 * NTU : nbk)) continue; // wave-uniform (TAIL: the tail block has its own step below)
                     SWG_T0()
                     // d_{b-1} (and x of its block) are requested BEFORE the lazy products and awaited after them; written as
                     // instructions because the compiler sinks the loads below the MFMAs (d would share d_prev's register)
@@ -196,12 +201,12 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"((unsigned)(size_t)&dbuf[par ^ 1][cl * 4 + lg]));
                     asm volatile("ds_read_b64 %0, %1" : "=v"(xold) : "v"((unsigned)(size_t)&xcell[4 * pb]));
                     const bool wrap = !(b + 1 < nbk); // the next block is block 0: tile 0, register 0
-                    const int tn = (t0 + 1) % NT;
-                    const int rn = (t0 == NT - 1) ? r0 + 1 : r0;
+                    const int tn = (t0 + 1) % NTU;
+                    const int rn = (t0 == NTU - 1) ? r0 + 1 : r0;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int uu = 0; uu < NT - 1 - (LATE ? 1 : 0); uu++) { // lazy products; the tile of the next block first
-                        const int t2 = (t0 + 1 + uu) % NT;
+                    for (int uu = 0; uu < NTU - 1 - (LATE ? 1 : 0); uu++) { // lazy products; the tile of the next block first
+                        const int t2 = (t0 + 1 + uu) % NTU;
                         SWG_TILE_FMA(t2, gzl_[t2], d_prev)
                     }
                     if (SWEEP_WG_XU) {
@@ -216,8 +221,8 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     SWG_MARK(2)
                     // operands of the next step, requested as soon as their registers are free: lazy = G[:, pb] (with this d) ...
 #pragma unroll
-                    for (int t2 = 0; t2 < NT; t2++) gzl_[t2] = gzl[(pb * NT + t2) * 64];
-                    if (LATE) gzlate[(t0 & 1) ^ 1] = gzl[(pb * NT + ((wrap ? 0 : t0 + 1) + NT - 1) % NT) * 64];
+                    for (int t2 = 0; t2 < NTU; t2++) gzl_[t2] = gzl[(pb * NTU + t2) * 64];
+                    if (LATE) gzlate[(t0 & 1) ^ 1] = gzl[(pb * NTU + ((wrap ? 0 : t0 + 1) + NTU - 1) % NTU) * 64];
                     // x before the urgent product (the fp64 MFMA holds up every VALU instruction behind it)
                     if (mine_cur) xcell[4 * pb] = xold + d;
                     SWG_MARK(3)
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     { // ... urgent = G[tile of the block after the next, b]
                         const int nb_ = wrap ? 0 : b + 1;
                         const bool nwrap = !(nb_ + 1 < nbk);
-                        const int ntn = ((nb_ % NT) + 1) % NT; // = the static tn of the next step
-                        const double gu = gzl[(b * NT + (nwrap ? 0 : ntn)) * 64];
+                        const int ntn = ((nb_ % NTU) + 1) % NTU; // = the static tn of the next step
+                        const double gu = gzl[(b * NTU + (nwrap ? 0 : ntn)) * 64];
                         gzu = (nwrap && ntn != 0) ? 0.0 : gu;
                         gzw = gu;
                     }
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     SWG_MARK(5)
                     if (LATE) {
                         __builtin_amdgcn_sched_barrier(0); // behind the store of far, not in front of it
-                        SWG_TILE_FMA((t0 + NT - 1) % NT, gzlate[t0 & 1], d_prev)
+                        SWG_TILE_FMA((t0 + NTU - 1) % NTU, gzlate[t0 & 1], d_prev)
                     }
                     if (!ALT) d_prev = d;
                     else if (wrap && (t0 & 1) == 0) dq[1] = dq[0], gzlate[0] = gzlate[1]; // the next step is block 0, an even step again
@@ -258,6 +263,35 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     if (b == 0) mine_cur = mine_next;
                     par ^= 1;
                 }
+            }
+            if (TAIL) {
+                // The chain wave is on the tail block (b = nbk - 1, no tile).  The step before applied d_{b-2} to tile 0 as if it were
+                // urgent (its `far` is not read), so the lazy products of this step go to the other tiles; the deltas of block
+                // b - 1 go to tile 0, whose first block is next.
+                const int b = nbk - 1;
+                SWG_T0()
+                double &d = dq[0], &d_prev = dq[1];
+                double xold = 0.0;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"((unsigned)(size_t)&dbuf[par ^ 1][cl * 4 + lg]));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(xold) : "v"((unsigned)(size_t)&xcell[4 * pb]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t2 = 1; t2 < NTU; t2++) SWG_TILE_FMA(t2, gzl_[t2], d_prev)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d), "+v"(xold));
+#pragma unroll
+                for (int t2 = 0; t2 < NTU; t2++) gzl_[t2] = gzl[(pb * NTU + t2) * 64];
+                if (mine_cur) xcell[4 * pb] = xold + d;
+                SWG_TILE_FMA(0, gzw, d)
+                gzu = gzl[(b * NTU + 1 % NTU) * 64]; // step 0: the tail block's deltas to the tile of block 1
+                gzw = gzu;
+                fbuf[par ^ 1][cl * 4 + lg] = mu[0];
+                d_prev = d;
+                SWG_SYNC(swg_work, swg_wait)
+                pb = b;
+                go = ctrl[par] != 0;
+                mine_next = ((actw[par] >> cl) & 1ull) != 0;
+                par ^= 1;
             }
         }
         if (mine_cur) xcell[4 * pb] += dbuf[par ^ 1][cl * 4 + lg]; // deltas of the very last step
@@ -280,11 +314,16 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         // constants of a block: fetched through the scalar cache one step AHEAD (before the barrier of the previous step)
         struct Consts {
             double gl[6]; // scaled G[4b+s2][4b+s], s2 > s
+            double gt[8]; // TAIL: scaled G[tail coordinate s][4b+g] at 4s + g
         };
         auto load_chain = [&](int b, Consts &c) {
             const auto *cb = cdat + b * SWEEP_WG_CONSTS;
 #pragma unroll
             for (int i = 0; i < 6; i++) c.gl[i] = cb[8 + i];
+            if (TAIL) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) c.gt[i] = cb[32 + i];
+            }
         };
         Consts cc;
         load_chain(0, cc);
@@ -295,6 +334,25 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
         double xdummy = 0.5;
         (void)xdummy;
         f64x2 x01 = *(const f64x2 *)&xrow[0], x23 = *(const f64x2 *)&xrow[2]; // x of the next block
+        // TAIL: the (scaled) gradients of the tail coordinates, (L1 - c) / G[q][q] + sum_j G'[q][j] x_j  (update_with_missing.cpp:39-41)
+        double mut[2] = {0.0, 0.0};
+        if (TAIL) {
+            const int tc = 4 * (nbk - 1), ccol = in_range ? col : a.col0;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (tc + s >= k) continue; // wave-uniform
+                double cv = 0.0;
+                for (int sl = 0; sl < a.nslabs; sl++) cv += a.Cx[(size_t)sl * a.slab_stride + (size_t)(tc + s) * a.ldc + ccol];
+                mut[s] = ((a.r2 != 0) ? a.r2 - cv : -cv) * cdat[(nbk - 1) * SWEEP_WG_CONSTS + s];
+            }
+            for (int bb = 0; bb < nbk; bb++) {
+                const auto *cb = cdat + bb * SWEEP_WG_CONSTS + 32;
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) mut[s] = __builtin_fma(cb[4 * s + g], xrow[4 * bb + g], mut[s]);
+            }
+        }
         {
             const unsigned long long bal = __ballot(act);
             if (lane == 0) actw[0] = bal;
@@ -331,6 +389,7 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                 SWG_EXTRA(SWEEP_WG_XA, xdummy)
                 SWG_MARK(1)
                 double m[4] = {f01[0] + near[0], f01[1] + near[1], f23[0] + near[2], f23[1] + near[3]};
+                if (TAIL && b == nbk - 1) m[0] = mut[0], m[1] = mut[1], m[2] = 0.0, m[3] = 0.0; // (always current: no far, no near)
 #ifdef SWEEP_WG_MARKS
                 asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
 #endif
@@ -354,6 +413,12 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
                     if (HAS_MASK && ((mword >> (4 * b + s)) & 1ull)) dd[s] = 0.0;
 #pragma unroll
                     for (int s2 = s + 1; s2 < 4; s2++) m[s2] = __builtin_fma(dd[s], gl[s2][s], m[s2]);
+                }
+                if (TAIL) { // the tail gradients see every block's deltas at once (the tail block's own included: G'[q][q] = 1)
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) mut[s] = __builtin_fma(cc.gt[4 * s + g], dd[g], mut[s]);
                 }
 #ifdef SWEEP_WG_MARKS
                 asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));

@@ -899,8 +899,14 @@ static void launch_sweep_wg(nnlm_handle *h, const SweepArgs &a, int nb)
 {
     if (FAST) {
         const int lds = sweep_wgf_lds_bytes(NT);
-        hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        sweep_scd_wgf_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
+        static int tail_env = getenv("NNLM_SWEEP_TAIL") ? atoi(getenv("NNLM_SWEEP_TAIL")) : 1;
+        if (NT >= 2 && tail_env && sweep_tail_coord(a.k) >= 0) { // k = 16 (NT - 1) + 1 or + 2: update waves with NT - 1 tiles
+            hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK, (NT >= 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            sweep_scd_wgf_kernel<NT, HAS_MASK, (NT >= 2)><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
+        } else {
+            hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            sweep_scd_wgf_kernel<NT, HAS_MASK, false><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
+        }
     } else {
         const int lds = sweep_wg_lds_bytes(NT);
         hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -13,10 +13,13 @@
 #include <random>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+#ifndef TAILV
+#define TAILV false
+#endif
 #if FASTV
-#define WGK sweep_scd_wgf_kernel
+#define WGK(NT_) sweep_scd_wgf_kernel<NT_, false, (TAILV && NT_ >= 2)>
 #else
-#define WGK sweep_scd_wg_kernel
+#define WGK(NT_) sweep_scd_wg_kernel<NT_, false>
 #endif
 template <int NT> static int run(int ncols, int k, int max_iter)
 {
@@ -45,7 +48,7 @@ template <int NT> static int run(int ncols, int k, int max_iter)
     }
 #endif
     const int lds = FASTV ? sweep_wgf_lds_bytes(NT) : sweep_wg_lds_bytes(NT);
-    CK(hipFuncSetAttribute((const void *)WGK<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void *)WGK(NT), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms1 = 0, ms2 = 0;
     for (int rep = 0; rep < 3; rep++) {
@@ -56,7 +59,7 @@ template <int NT> static int run(int ncols, int k, int max_iter)
         a.Xout = dO2;
         hipEventRecord(e0);
         sweep_consts_kernel<<<1, 256>>>(dG, KP, k, a.r0, a.r1, dK, FASTV ? 1 : 0);
-        WGK<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
+        WGK(NT)<<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
         hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms2, e0, e1);
     }
     CK(hipGetLastError());
@@ -64,7 +67,7 @@ template <int NT> static int run(int ncols, int k, int max_iter)
         unsigned long long *dT, T[18];
         CK(hipMalloc(&dT, 144)); CK(hipMemset(dT, 0, 144));
         SweepArgs b2 = a; b2.op = dT; b2.op_mode = 0; b2.Xout = dO2;
-        WGK<NT, false><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(b2, dK);
+        WGK(NT)<<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(b2, dK);
         CK(hipMemcpy(T, dT, 144, hipMemcpyDeviceToHost));
         const double steps = (double)max_iter * ((k + 3) / 4);
         printf("  per step (100 MHz ticks x 24 ~ cycles): chain wave work %.1f wait %.1f | update wave work %.1f wait %.1f  [raw counter units]\n",
