@@ -477,42 +477,48 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
     }
     __syncthreads(); // x image final
 
+    // The epilogue reads the launch arguments AGAIN from the kernarg segment: held in SGPRs across the step loops they push
+    // the chain wave's block constants out (8 v_readlane per step to get the spilled pointer of the constants image back).
+    const SweepArgs *ap = (const SweepArgs *)__builtin_amdgcn_kernarg_segment_ptr(); // first kernel parameter
+    asm volatile("" : "+s"(ap));
+    const SweepArgs &ea = *ap;
+
     float xmax = 0.0f;
     for (int e = tid; e < SWEEP_WG_COLS * KP; e += SWEEP_WG_THREADS) {
         const int q = e / SWEEP_WG_COLS, c = e % SWEEP_WG_COLS, col = col_base + c;
-        if (q < k && col < a.ncols) {
+        if (q < k && col < ea.ncols) {
             const double xv = xl[c * XS + q];
             xmax = fmaxf(xmax, fabsf((float)xv));
-            a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
-            if (a.op_mode == 1) {
-                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
-                else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
+            ea.Xout[(size_t)q * ea.ldo + (col - ea.ocol0)] = xv;
+            if (ea.op_mode == 1) {
+                if (ea.op_f64) ((double *)ea.op)[(size_t)q * ea.op_ld + col] = xv;
+                else ((float *)ea.op)[(size_t)q * ea.op_ld + col] = (float)xv;
             }
         }
     }
-    if (a.op_mode == 2) { // [col][op_ld], kq fastest: consecutive threads write consecutive kq of one column
+    if (ea.op_mode == 2) { // [col][op_ld], kq fastest: consecutive threads write consecutive kq of one column
         for (int e = tid; e < SWEEP_WG_COLS * KP; e += SWEEP_WG_THREADS) {
             const int c = e / KP, q = e % KP, col = col_base + c;
-            if (q < k && col < a.ncols) {
+            if (q < k && col < ea.ncols) {
                 const double xv = xl[c * XS + q];
-                if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
-                else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
+                if (ea.op_f64) ((double *)ea.op)[(size_t)col * ea.op_ld + q] = xv;
+                else ((float *)ea.op)[(size_t)col * ea.op_ld + q] = (float)xv;
             }
         }
     }
-    if (a.maxbits) {
+    if (ea.maxbits) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
-        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
+        if (lane == 0 && xmax > 0.0f) atomicMax(ea.maxbits, __float_as_uint(xmax));
     }
-    if (a.gram_slabs) {
+    if (ea.gram_slabs) {
         // Gram partial sums of this workgroup's columns (what gram_partial_kernel, k_gram.h, would compute after reading the
         // factor back; rows of padded / out-of-range columns of the x image are zero): X X^T over the 48 columns with
         // v_mfma_f64_16x16x4_f64, upper tiles dealt to the four wavefronts, same slab layout as gram_partial_kernel.
         // ~1 us per workgroup.  The slabs are folded by gram_fold_kernel (k_gram.h) -- NOT here: a "last workgroup of a
         // group adds them" step needs __threadfence(), and two of those per workgroup cost 65 us of the kernel's tail.
         const int l15 = lane & 15, lg = lane >> 4;
-        double *slab = a.gram_slabs + (size_t)blockIdx.x * KP * KP;
+        double *slab = ea.gram_slabs + (size_t)blockIdx.x * KP * KP;
         int tix = 0;
 #pragma unroll
         for (int ta = 0; ta < NT; ta++)
@@ -530,8 +536,8 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
             }
     }
 #ifdef SWEEP_WG_TIMING
-    if (a.op && blockIdx.x == 0 && lane == 0 && (wave == CW || wave == 1)) {
-        unsigned long long *dbg = (unsigned long long *)a.op; // harness: [role][work, wait]
+    if (ea.op && blockIdx.x == 0 && lane == 0 && (wave == CW || wave == 1)) {
+        unsigned long long *dbg = (unsigned long long *)ea.op; // harness: [role][work, wait]
         dbg[(wave == CW ? 0 : 2)] = swg_work;
         dbg[(wave == CW ? 0 : 2) + 1] = swg_wait;
 #ifdef SWEEP_WG_MARKS
@@ -541,6 +547,6 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wgf_kernel(const S
 #endif
     if (wave == CW) {
         long long tot = wave_sum_ll((long long)t_lane);
-        if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
+        if (lane == 0 && tot) atomicAdd(ea.sweeps, (unsigned long long)tot);
     }
 }
