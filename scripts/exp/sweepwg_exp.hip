@@ -1,6 +1,8 @@
 // Standalone check + timing of sweep_scd_wg_kernel against sweep_scd_mfma_kernel (not part of the product).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o sweepwg_exp sweepwg_exp.hip ; ./sweepwg_exp [ncols] [k] [max_iter]
+#ifndef SWEEP_NO_TIMING
 #define SWEEP_WG_TIMING 1
+#endif
 #ifndef FASTV
 #define FASTV true
 #endif
