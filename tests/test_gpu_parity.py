@@ -471,7 +471,8 @@ def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, met
 
 # ---- the restructured SCD sweep of the f32 mode (k_sweep_wgf.h): masks, columns that finish early, ragged shapes ------
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(300, 101, 9), (257, 1000, 17), (120, 49, 33), (400, 530, 50), (90, 97, 64)])
+@pytest.mark.parametrize("shape", [(300, 101, 9), (257, 1000, 17), (70, 50, 18), (120, 49, 33), (64, 97, 34), (130, 60, 49), (400, 530, 50),
+                                   (90, 97, 64)])  # 17/18, 33/34, 49/50: the tail-block form with 1, 2, 3 update tiles
 @pytest.mark.parametrize("inner,itol", [(50, 1e-3), (7, 1e-9), (200, 1e-6), (0, 1e-9), (1, -1.0)])
 def test_fast_sweep_with_masks_and_early_finishers(shape, inner, itol):
     n, m, k = shape
