@@ -420,13 +420,14 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("method", [1, 2])
-def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, method):
+@pytest.mark.parametrize("k", [13, 50])  # 50: the tail-block form of the fast sweep on column slabs that do not start at 0
+def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, method, k):
     """Shard arithmetic of the multi-GPU path with `world` virtual ranks on one device: every rank contracts its slab
     (phase 1), the host stand-in for ncclAllReduce sums the [Gram | cross-product] buffers, every rank sweeps ITS columns
     (phase 2), the stand-in for ncclAllGather distributes the packed slabs, every rank unpacks (phase 3).  All ranks must
     end with identical factors, equal to the single-rank result up to the all-reduce's summation order."""
     rng = np.random.default_rng(world + method)
-    n, m, k = 500, 333, 13
+    n, m = 500, 333
     A = rng.random((n, m))
     W0, H0 = rng.random((n, k)), rng.random((k, m))
     Wm = rng.random((n, k)) < 0.05
