@@ -7,7 +7,7 @@
  * (reference src/RcppExports.cpp:10-27, :29-54, :56-65; called from R/RcppExports.R:4-10).
  * `nnlm_c_nnmf()` / `nnlm_c_nnlm()` below take exactly those arguments as plain pointers and
  * sizes and return exactly the members of the reference's named result lists
- * (src/nnmf.cpp:211-219, src/nnlm.cpp:49-52).  nnlm_amd/csrc/r_glue.c shows the Rinternals-only
+ * (src/nnmf.cpp:211-219, src/nnlm.cpp:49-52).  pkg/src/r_glue.c shows the Rinternals-only
  * .Call stub a maintainer adds on the R side; nnlm_amd/_lib.py is the ctypes binding used here.
  *
  * Conventions (all taken from the reference):

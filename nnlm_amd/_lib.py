@@ -1,6 +1,6 @@
 """ctypes binding of libnnlm_mi355x.so (include/nnlm_mi355x.h).
 
-This is the Python stand-in for the R-side ``.Call`` stub (nnlm_amd/csrc/r_glue.c): it passes
+This is the Python stand-in for the R-side ``.Call`` stub (pkg/src/r_glue.c): it passes
 plain pointers and sizes across the C ABI, nothing else.  There is deliberately NO fallback: if
 the shared library is missing or no gfx950 device is present, every entry raises.
 """

@@ -39,10 +39,12 @@ static void cb_progress(void *ctx, unsigned done, unsigned total)
     }
 }
 static void cb_print(void *ctx, const char *text) { (void)ctx; Rprintf("%s", text); }                 /* Rprintf */
-static void cb_warning(void *ctx, const char *text) { (void)ctx; Rf_warning("%s", text); }             /* Rcpp::warning */
 static double cb_unif(void *ctx) { (void)ctx; return unif_rand(); }                                    /* arma::randu -> R RNG */
 
-static const nnlm_callbacks k_callbacks = {NULL, cb_check_interrupt, cb_progress, cb_print, cb_warning, cb_unif};
+/* The warning callback stays NULL: Rf_warning() may long-jump (options(warn = 2), calling handlers) and must not do so
+ * through the library's C++ frames while the device handle is alive.  nnlm_c_nnmf() reports `warned`; the warning of
+ * reference src/nnmf.cpp:208-209 is raised below, after the library has returned and released the device. */
+static const nnlm_callbacks k_callbacks = {NULL, cb_check_interrupt, cb_progress, cb_print, NULL, cb_unif};
 
 static SEXP named_list(int n, const char **names)
 {
@@ -92,6 +94,7 @@ SEXP _NNLM_c_nnmf(SEXP ASEXP, SEXP kSEXP, SEXP WSEXP, SEXP HSEXP, SEXP WmSEXP, S
     SET_VECTOR_ELT(out, 4, Rf_xlengthgets(terr, n_trace));
     SET_VECTOR_ELT(out, 5, Rf_xlengthgets(ep, n_trace));
     SET_VECTOR_ELT(out, 6, Rf_ScalarInteger((int)n_iteration));
+    if (warned) Rf_warning("Target tolerance not reached. Try a larger max.iter."); /* Rcpp::warning, src/nnmf.cpp:208-209 */
     UNPROTECT(7);
     return out;
 }

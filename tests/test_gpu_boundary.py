@@ -1,0 +1,202 @@
+"""GPU tests of the boundary's loose ends: host callbacks (interrupt, progress bar, verbose = 2 table), the stacked
+known-profile / mask inputs of R/misc.R:48-129, W.norm (R/nnmf.R:197-205) and the vignette's rank selection by
+imputation (vignettes/Fast-And-Versatile-NMF.Rmd:613-694) -- all through the C ABI, checked against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import relF  # noqa: E402
+import nnlm_amd  # noqa: E402
+from nnlm_amd import _lib, api  # noqa: E402
+from oracle import ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed=5, n=80, m=60, k=4):
+    rng = np.random.default_rng(seed)
+    A = rng.random((n, k)) @ rng.random((k, m)) + 0.01 * rng.random((n, m))
+    return A, 0.01 * rng.random((n, k)), 0.01 * rng.random((k, m))
+
+
+# ---- callbacks -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [_lib.PREC_F64, _lib.PREC_F32])
+@pytest.mark.parametrize("stop_at", [0, 1, 4, 5])  # 4: a trace iteration has just queued a speculative W half-step
+def test_check_interrupt_aborts_at_the_iteration_and_leaves_the_handle_consistent(prec, stop_at):
+    """Rcpp::checkUserInterrupt() is polled once per outer iteration before any work of that iteration
+    (src/nnmf.cpp:111).  A non-zero answer at the top of iteration i must return NNLM_ERR_INTERRUPT with exactly i
+    iterations applied -- in particular the speculative W half-step queued behind a trace iteration must be dropped --
+    and the resident handle must remain usable: continuing from there reproduces an uninterrupted run."""
+    A, W0, H0 = _problem()
+    z = [0.0, 0.0, 0.0]
+    calls = []
+
+    def intr():
+        calls.append(len(calls))
+        return len(calls) - 1 == stop_at
+
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(4, W0, H0)
+        cb = _lib.make_callbacks(check_interrupt=intr)
+        with pytest.raises(_lib.NnlmError) as ei:
+            h.run(z, z, 10, -1.0, 0, False, 5, 1e-9, 1, 1, callbacks=cb)
+        assert ei.value.code == 3 and len(calls) == stop_at + 1
+        Wi, Hi = h.get_factors()
+        sweeps_i = h.take_sweeps(reset=False)
+        # continue for the remaining iterations on the same handle
+        h.run(z, z, 10 - stop_at, -1.0, 0, False, 5, 1e-9, 1, 1)
+        Wc, Hc = h.get_factors()
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(4, W0, H0)
+        if stop_at:
+            h.iterate(stop_at, z, z, 5, 1e-9, 1)
+        Wr, Hr = h.get_factors()
+        h.iterate(10 - stop_at, z, z, 5, 1e-9, 1)
+        Wf, Hf = h.get_factors()
+    tol = 1e-12 if prec == _lib.PREC_F64 else 1e-6
+    assert relF(Wi, Wr) < tol and relF(Hi, Hr) < tol          # exactly stop_at iterations were applied
+    assert relF(Wc, Wf) < 10 * tol and relF(Hc, Hf) < 10 * tol  # and the handle carried on correctly
+    assert sweeps_i <= (80 + 60) * 5  # at most the open trace window's sweeps; never the dropped half-step's
+
+
+def test_progress_callback_counts_every_iteration(monkeypatch):
+    """verbose == 1: RcppProgress is incremented once per outer iteration (src/nnmf.cpp:60,112)."""
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    A, W0, H0 = _problem()
+    seen = []
+    cb = _lib.make_callbacks(progress=lambda d, t: seen.append((d, t)))
+    r = nnlm_amd.c_nnmf(A, 4, W0, H0, None, None, [0, 0, 0], [0, 0, 0], 7, -1.0, 1, 1, False, 5, 1e-9, 1, 2, callbacks=cb)
+    assert r["n_iteration"] == 7 and seen == [(i + 1, 7) for i in range(7)]
+    seen.clear()
+    nnlm_amd.c_nnmf(A, 4, W0, H0, None, None, [0, 0, 0], [0, 0, 0], 7, -1.0, 1, 0, False, 5, 1e-9, 1, 2, callbacks=cb)
+    assert seen == []  # verbose 0 and 2 do not drive the bar
+
+
+@pytest.mark.parametrize("method,trace", [(1, 2), (4, 3)])
+def test_verbose2_table_text(monkeypatch, method, trace):
+    """verbose == 2: the Rprintf table of src/nnmf.cpp:100-104,155-156,188-189,194-198 -- header, one row per trace entry
+    (iteration number, MSE, MKL, target, relative error in the reference's formats), footer."""
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    A, W0, H0 = _problem()
+    out = []
+    cb = _lib.make_callbacks(print_fn=out.append)
+    args = (A, 4, W0, H0, None, None, [0.01, 0, 0], [0, 0, 0.01], 6, -1.0, 1, 2, False, 5, 1e-9, method, trace)
+    r = nnlm_amd.c_nnmf(*args, callbacks=cb)
+    o = ref.c_nnmf(*args)
+    text = "".join(out)
+    head = "\n%10s | %10s | %10s | %10s | %10s\n" % ("Iteration", "MSE", "MKL", "Target", "Rel. Err.")
+    rule = "--------------------------------------------------------------\n"
+    foot = "%10s | %10s | %10s | %10s | %10s\n\n" % ("Iteration", "MSE", "MKL", "Target", "Rel. Err.")
+    assert text.startswith(head + rule) and text.endswith(rule + foot)
+    rows = text[len(head + rule):-len(rule + foot)].splitlines()
+    assert len(rows) == len(o["mse_error"]) == len(r["mse_error"])
+    its = [i + 1 for i in range(6) if i % trace == 0]
+    if (6 - 1) % trace != 0:
+        its.append(6 + 1)  # the closing block prints i+1 with i == max_iter (src/nnmf.cpp:188-189)
+    last = 1e99
+    for row, it, mse, mkl, terr in zip(rows, its, o["mse_error"], o["mkl_error"], o["target_error"]):
+        rel = 2 * (last - terr) / (last + terr + 1e-16)
+        last = terr
+        cells = [c.strip() for c in row.split("|")]
+        assert int(cells[0]) == it
+        assert cells[1] == ("%10.4f" % mse).strip() and cells[2] == ("%10.4f" % mkl).strip() and cells[3] == ("%10.4f" % terr).strip()
+        assert abs(float(cells[4]) - rel) <= 0.35 * abs(rel)  # "%10.g": one significant digit
+        assert len(row) == 5 * 10 + 4 * 3
+
+
+def test_warning_callback_and_flag(monkeypatch):
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    A, W0, H0 = _problem()
+    msgs = []
+    cb = _lib.make_callbacks(warning=msgs.append)
+    r = nnlm_amd.c_nnmf(A, 4, W0, H0, None, None, [0, 0, 0], [0, 0, 0], 3, 1e-12, 1, 0, True, 5, 1e-9, 1, 1, callbacks=cb)
+    assert r["warning"] and msgs == ["Target tolerance not reached. Try a larger max.iter."]
+    msgs.clear()
+    r = nnlm_amd.c_nnmf(A, 4, W0, H0, None, None, [0, 0, 0], [0, 0, 0], 3, 1e-12, 1, 0, False, 5, 1e-9, 1, 1, callbacks=cb)
+    assert not r["warning"] and msgs == []
+
+
+def test_default_precision_of_the_one_shot_entries_is_fp64(monkeypatch):
+    """The .Call boundary defaults to the strict mode (the reference is fp64 and its testthat vectors are held at 1.5e-8);
+    NNLM_PRECISION=f32 opts into the fp32-operand mode."""
+    monkeypatch.delenv("NNLM_PRECISION", raising=False)
+    rng = np.random.default_rng(3)
+    x = rng.random((30, 5))
+    b = np.array([1.0, 2.0, 0.0, 0.5, 3.0])
+    r = nnlm_amd.c_nnlm(x, x @ b, [0, 0, 0], None, np.ones((5, 1)), 10000, 1e-12, 1, 1)
+    assert np.max(np.abs(r["coefficient"].ravel() - b)) < 1e-9
+    monkeypatch.setenv("NNLM_PRECISION", "f32")
+    r32 = nnlm_amd.c_nnlm(x, x @ b, [0, 0, 0], None, np.ones((5, 1)), 10000, 1e-12, 1, 1)
+    assert 1e-12 < np.max(np.abs(r32["coefficient"].ravel() - b)) < 1e-4
+
+
+# ---- stacked known profiles, masks, W.norm through the R-interface mirror ------------------------------------------
+@pytest.mark.parametrize("pname,tol", [("f64", 1e-8), ("f32", 1e-4)])
+def test_known_profiles_and_masks_stacked_like_reformat_input(monkeypatch, pname, tol):
+    """tests/testthat/test-nnmf.R:41-47: nnmf(A2, k, init = list(W0 = W1, H0 = H2)) -- K = k + k1 + k2 columns, W0 and
+    H0 blocks fully masked (R/misc.R:60-82,119-128) so they come back bit-identical, partially masked W/H blocks next to
+    them.  The same 17 arguments go to the GPU and to the oracle."""
+    monkeypatch.setenv("NNLM_PRECISION", pname)
+    rng = np.random.default_rng(21)
+    n, m, k, k1, k2 = 120, 70, 3, 2, 1
+    W, H = rng.random((n, k)), rng.random((k, m))
+    W1, H1 = rng.random((n, k1)), rng.random((k1, m))
+    W2, H2 = rng.random((n, k2)), np.ones((k2, m))
+    A2 = W @ H + W1 @ H1 + W2 @ H2
+    mask = {"W": rng.random((n, k)) < 0.1, "H": rng.random((k, m)) < 0.1}
+    kw = dict(init={"W0": W1, "H0": H2}, mask=mask, max_iter=40, rel_tol=-1, inner_max_iter=20, show_warning=False)
+    args, ctx = api.prepare_nnmf(A2, k, rng=np.random.default_rng(1), **kw)
+    assert args[1] == k + k1 + k2
+    o = api.finish_nnmf(ref.c_nnmf(*args), ctx)
+    r = api.finish_nnmf(nnlm_amd.c_nnmf(*args), ctx)
+    assert r.W.shape == (n, k + k1 + k2) and r.H.shape == (k + k1 + k2, m)
+    assert np.array_equal(r.W[:, k:k + k1], W1) and np.array_equal(r.H[k + k1:], H2)  # fixed profiles untouched
+    assert np.all(r.W[:, :k][mask["W"]] == 0) and np.all(r.H[:k][mask["H"]] == 0)
+    assert relF(r.W @ r.H, o.W @ o.H) < tol and relF(r.W, o.W) < 50 * tol and relF(r.H, o.H) < 50 * tol
+    assert np.allclose(r.mse, o.mse, rtol=100 * tol, atol=1e-14)
+    if pname == "f64":
+        assert np.array_equal(r.average_epochs, o.average_epochs)
+
+
+@pytest.mark.parametrize("W_norm", [1, 2, np.inf])
+def test_w_norm_rescaling(monkeypatch, W_norm):
+    """R/nnmf.R:197-205: columns of W rescaled to unit W.norm, rows of H scaled back; W H unchanged."""
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    A, W0, H0 = _problem()
+    r0 = api.nnmf(A, 4, init={"W": W0, "H": H0}, max_iter=20, rel_tol=-1, show_warning=False)
+    r = api.nnmf(A, 4, init={"W": W0, "H": H0}, max_iter=20, rel_tol=-1, show_warning=False, W_norm=W_norm)
+    norms = r.W.max(axis=0) if np.isinf(W_norm) else np.sum(r.W ** W_norm, axis=0) ** (1.0 / W_norm)
+    assert np.allclose(norms, 1.0, rtol=1e-12)
+    assert relF(r.W @ r.H, r0.W @ r0.H) < 1e-12
+
+
+def test_rank_selection_by_imputation_matches_oracle(monkeypatch):
+    """vignettes/Fast-And-Versatile-NMF.Rmd:640-665 at the vignette's size (400 x 50, true rank 3, 30 % of the entries held
+    out): for k = 1..6 the held-out MSE of the GPU factorisation equals the oracle's, and is minimised at the true rank."""
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    rng = np.random.default_rng(678)
+    n, m, k0 = 400, 50, 3
+    A = rng.random((n, k0)) @ (10 * rng.random((k0, m))) + rng.standard_normal((n, m))
+    A[A < 0] = 0
+    ind = rng.choice(A.size, int(0.3 * A.size), replace=False)
+    A2 = A.copy()
+    A2.ravel()[ind] = np.nan
+    held, held_o = [], []
+    for k in range(1, 7):
+        g = np.random.default_rng(100 + k)
+        init = {"W": 0.01 * g.random((n, k)), "H": 0.01 * g.random((k, m))}
+        kw = dict(init=init, max_iter=60, rel_tol=1e-4, show_warning=False)
+        r = api.nnmf(A2, k, **kw)
+        args, ctx = api.prepare_nnmf(A2, k, **kw)
+        o = api.finish_nnmf(ref.c_nnmf(*args), ctx)
+        assert r.n_iteration == o.n_iteration
+        held.append(float(np.mean(((r.W @ r.H).ravel()[ind] - A.ravel()[ind]) ** 2)))
+        held_o.append(float(np.mean(((o.W @ o.H).ravel()[ind] - A.ravel()[ind]) ** 2)))
+        assert abs(r.mse[-1] - o.mse[-1]) < 1e-8 * o.mse[-1]
+    assert np.allclose(held, held_o, rtol=1e-6)
+    assert int(np.argmin(held)) + 1 == k0

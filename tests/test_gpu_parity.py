@@ -323,7 +323,6 @@ def test_config2_full_size_one_iteration_vs_oracle_and_properties():
         assert relF(W1, Wt_ref.T) < 1e-4 and relF(H1, H_ref) < 1e-4
         assert abs(sweeps - (it1 + it2)) <= 0.001 * (it1 + it2)
         mse_prev = h.errors()[0]
-        ah = W1[:64] @ H1[:, :64]
         for _ in range(3):
             h.iterate(1, z, z, 50, 1e-9, 1)
             mse = h.errors()[0]
@@ -331,10 +330,12 @@ def test_config2_full_size_one_iteration_vs_oracle_and_properties():
             mse_prev = mse
         W, H = h.get_factors()
         assert np.all(W >= 0) and np.all(H >= 0) and np.isfinite(W).all() and np.isfinite(H).all()
-        # the device-side error block agrees with a host evaluation on a 512 x 512 corner
-        assert ah.shape == (64, 64)
-        sub = np.mean((A[:2000] - W[:2000] @ H) ** 2)
-        assert abs(sub - mse_prev) < 0.02 * mse_prev
+        # the device-side error block (errors_f32_kernel) against a host evaluation over the whole matrix
+        host = 0.0
+        for j0 in range(0, m, 1000):
+            host += float(np.sum((A[:, j0:j0 + 1000] - W @ H[:, j0:j0 + 1000]) ** 2))
+        host /= float(n) * m
+        assert abs(host - mse_prev) < 1e-6 * host, (host, mse_prev)
 
 
 # ---- multi-GPU shard arithmetic with virtual ranks on one device ---------------------------------------
