@@ -1,4 +1,5 @@
-// k_kl.h -- per-column solvers for the KL-divergence methods, fp64.
+// k_kl.h -- per-column solvers for the KL-divergence methods: kl_update_kernel (strict fp64, state in registers),
+// kl_tile_kernel (fp32-operand mode), kl_stream_kernel (no size limits).
 //
 // Reference: scd_kl_update (src/base_algorithms.cpp:71-116) and lee_kl_update (src/base_algorithms.cpp:119-151) as
 // called from update() (src/update_with_missing.cpp:47-49) and, with the contraction restricted to the finite
@@ -167,176 +168,298 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     if (tid == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// NNLM_PREC_F32 variant.  Same sequence of coordinate updates as above; what changes is the arithmetic of the O(p) part
-// (the mode already stores A in fp32) and the amount of cached-operand traffic:
-//   * the state vector y and the data column b are fp32 registers; the quotients b/(y+eps), w/(y+eps) use
-//     v_rcp_f32 (1 ulp) instead of an fp64 division (~20 instructions at 8 issue cycles each);
-//   * rows of the fixed factor are read from its fp32 GEMM-operand copy (Yf), half the bytes of the fp64 master;
-//   * a block solves C = 2 adjacent columns, so that every row of the fixed factor fetched from L2 serves two
-//     columns (the row traffic, ncols*k*p*4/C bytes per sweep, is what bounds this kernel);
-//   * per-thread partial sums are fp32 over EPT terms, then fp64 across the block; the scalar coordinate update
-//     (:128-150 above) stays fp64.
-struct KlFastArgs {
-    KlArgs a;
-    const float *Yf; // [KP][ldyf] fp32 copy of the fixed factor, contraction index fastest
+// ==================================================================================================================
+// kl_tile_kernel -- the KL solvers of the fp32-operand mode (replaces kl_fast_kernel).
+//
+// What bounded kl_fast_kernel (config 3, 34 ms per iteration): 40 row elements + 160 state registers per thread spilled,
+// every row of the fixed factor was fetched from L2 by plain per-lane loads that could not be issued ahead, the data
+// column and the state of the W half-step were read with a stride, and every coordinate step reduced NV*C fp64 values
+// with 6 two-dword shuffles each.  Here:
+//   * a 512-thread block owns C columns; the state vector y (+eps folded in once) and the data column b of each column
+//     stay in registers as float4 chunks (thread t owns float4s t, t+512, ...: coalesced 16-byte loads, both from
+//     contraction-contiguous layouts: A / What for the H half-step, their transposed fp32 copies for the W half-step);
+//   * row q of the fixed factor is staged in LDS by global_load_lds one coordinate step AHEAD (two row buffers; every
+//     thread reads back exactly the slots its own wavefront loaded, so a counted s_waitcnt vmcnt is the only
+//     synchronisation the rows need) and serves all C columns and both passes of the step; a row is padded to whole
+//     64 x 16-byte wavefront pieces so that "does this piece exist" is a scalar branch, never a per-lane select;
+//   * pass A: r = v_rcp_f32(y), s += w * (b * r) (Lee) on float4 lanes, 4 partial sums per column; the wave sum is 6 DPP
+//     adds in fp32, the 8 wave totals are added in fp64; ONE barrier per coordinate step; pass B: y += coef * w;
+//   * the row sums of the fixed factor ("sumW") do not depend on the state: one k-vector per half-step (dense) or one
+//     per column over its non-missing entries (kl_sumw_cols_kernel) -- the missing entries themselves need no predicate
+//     in the loop (b = 0 there, so they add nothing to the sums the reference restricts to non_missing);
+//   * rank is not limited by a 64-bit word: coordinates live in LDS, masks are mw words per column.
+// |y| in the quotient (a free source modifier): a state entry that rounding pushed below zero cannot flip a sign.
+// VALU bound: 3 plain + 1 transcendental instruction per element and coordinate = 14.9-17.7 cycles per 64 elements per
+// SIMD measured in isolation (scripts/exp/valu_exp.hip), i.e. ~1.0 ms per half-step at config 3.
+// Arithmetic differences from kl_update_kernel: fp32 state and quotients as kl_fast_kernel; tmp = num / den through
+// v_rcp_f64 + one Newton step; the rel-change test 2|d|/(..) > tol without the division.
+struct KlTileArgs {
+    const float *Adata; // column c at Adata + c * lda, contraction index contiguous
+    size_t lda;
+    const float *Yinit; // same layout: starting state vectors y = Yt^T x of all columns (wh_store_kernel)
+    const float *Yf;    // [k][ldyf] fp32 fixed factor, contraction index contiguous, zero beyond p
     int ldyf;
-    const float *Yinit; // starting state vectors of all columns in the layout of A (wh_store_kernel); NULL: k passes over Yf
+    int p, ncols, k;
+    const double *X;
+    double *Xout;
+    int ldx;
+    const double *sumw;      // [k]: sum over the contraction index of row q of the fixed factor, or
+    const double *sumw_cols; // [ncols][ldsw]: the same restricted to the non-missing entries of each column (NULL: dense)
+    int ldsw;
+    double r0, r1, r2;
+    const unsigned long long *mask; // [ncols][mw] or NULL
+    int mw;
+    unsigned max_iter;
+    double rel_tol;
+    void *op;
+    int op_mode, op_ld;
+    unsigned long long *sweeps;
 };
 
-template <int EPT, int METHOD, int C>
-__global__ __launch_bounds__(KL_THREADS) void kl_fast_kernel(const KlFastArgs fa)
+template <int CTRL, int RMASK> __device__ static inline float kl_dpp(float oldv, float v)
 {
-    const KlArgs &a = fa.a;
-    constexpr int NV = (METHOD == 4) ? 2 : 3; // sums per column: {num, sumW} or {a, b, sumW}
-    __shared__ double xs[C][64];
-    __shared__ double red[2 * NV * C * 8];
-    const int tid = threadIdx.x;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v), CTRL, RMASK, 0xF, false));
+}
+// sum over the wavefront, valid in lane 63
+__device__ static inline float kl_wave_total(float v)
+{
+    v += kl_dpp<0xB1, 0xF>(0.f, v);  // quad_perm [1,0,3,2]
+    v += kl_dpp<0x4E, 0xF>(0.f, v);  // quad_perm [2,3,0,1]
+    v += kl_dpp<0x141, 0xF>(0.f, v); // row_half_mirror
+    v += kl_dpp<0x140, 0xF>(0.f, v); // row_mirror: every lane of a row holds the row sum
+    v += kl_dpp<0x142, 0xA>(0.f, v); // row_bcast15 into rows 1 and 3
+    v += kl_dpp<0x143, 0xC>(0.f, v); // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ static inline void kl_wait_vmcnt(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+#define KLT_THREADS 512
+// dynamic LDS of kl_tile_kernel: two row buffers, coordinates and row sums of the C columns, reduction scratch
+// (a staged row is a whole number of 64 x 16-byte wavefront pieces: which pieces exist is then wave-uniform)
+__host__ __device__ static inline int kl_tile_p4(int p) { return ((p + 3) / 4 + 63) / 64 * 64; }
+__host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0)
+{
+    return 2 * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * 8 * 4 + (size_t)C * mw_masked * 8;
+}
+
+template <int EPT4, int C, int METHOD>
+__global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a)
+{
+    constexpr int NV = (METHOD == 4) ? 1 : 2; // sums per column and step: {num} or {a, b}
+    extern __shared__ __attribute__((aligned(16))) unsigned char kl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: scalar branches)
+    const int k = a.k, P4 = kl_tile_p4(a.p); // float4 slots per row, padded to whole wavefront pieces (the arrays are padded further)
+    const int rowb = P4 * 16;
+    double *xs = (double *)(kl_smem + 2 * (size_t)rowb); // [C][k]
+    double *sws = xs + C * k;                            // [C][k]
+    float *red = (float *)(sws + C * k);                 // [2][NV * C][8]
+    unsigned long long *mks = (unsigned long long *)(red + 2 * 2 * C * 8); // [C][mw] mask words of the block's columns (a.mask only)
     const int col0 = blockIdx.x * C;
-    const int k = a.k, p = a.p;
-    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
     const float tiny = (float)NNLM_TINY;
 
-    unsigned long long mword[C];
-    bool live[C]; // column exists and is not fully masked
+    // pieces e = 0 .. nlw-1 of a row (float4 slots e * 512 + 64 * wave + lane) belong to this wavefront: it loads them, reads
+    // them back and owns the matching chunks of the state
+    int nlw = 0;
+#pragma unroll
+    for (int e = 0; e < EPT4; e++) nlw += (e * KLT_THREADS + wave * 64 < P4) ? 1 : 0;
+    const int voff = lane * 16;
+    auto issue = [&](int q, int bufsel) {
+        const unsigned char *row = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024; // wave-uniform
+#pragma unroll
+        for (int e = 0; e < EPT4; e++)
+            if (e < nlw) glds16(row + (size_t)e * (KLT_THREADS * 16) + voff, kl_smem + (size_t)bufsel * rowb + (size_t)(e * KLT_THREADS + wave * 64) * 16);
+    };
+
+    bool live[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const int col = col0 + c;
-        mword[c] = (a.mask && col < a.ncols) ? a.mask[col] : 0ull;
-        live[c] = col < a.ncols && !(a.mask && ((mword[c] & kmask) == kmask));
-        if (tid < 64) xs[c][tid] = (tid < k && col < a.ncols) ? a.X[(size_t)tid * a.ldx + col] : 0.0;
+        live[c] = col < a.ncols;
+        if (live[c] && a.mask) { // all coordinates masked: 0 sweeps, values copied through (src/update_with_missing.cpp:33)
+            bool all = true;
+            for (int w = 0; w < a.mw; w++) {
+                const int bits = (k - 64 * w >= 64) ? 64 : k - 64 * w;
+                const unsigned long long km = (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull);
+                all = all && ((a.mask[(size_t)col * a.mw + w] & km) == km);
+            }
+            live[c] = !all;
+        }
     }
-    __syncthreads();
+    if (a.mask)
+        for (int e = tid; e < C * a.mw; e += KLT_THREADS) mks[e] = (col0 + e / a.mw < a.ncols) ? a.mask[(size_t)col0 * a.mw + e] : ~0ull;
+    for (int e = tid; e < C * k; e += KLT_THREADS) {
+        const int c = e / k, q = e - c * k, col = col0 + c;
+        xs[e] = (col < a.ncols) ? a.X[(size_t)q * a.ldx + col] : 0.0;
+        sws[e] = (col < a.ncols) ? (a.sumw_cols ? a.sumw_cols[(size_t)col * a.ldsw + q] : a.sumw[q]) : 1.0;
+    }
 
-    float y[C][EPT], b[C][EPT];
-    unsigned long long vbits[C];
+    f32x4 y[C][EPT4], b[C][EPT4];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const int col = (col0 + c < a.ncols) ? col0 + c : col0;
-        const float *Acol = (const float *)a.A + (size_t)col * a.a_col_stride;
-        vbits[c] = 0ull;
+        const f32x4 *Ac = (const f32x4 *)(a.Adata + (size_t)col * a.lda), *Yc = (const f32x4 *)(a.Yinit + (size_t)col * a.lda);
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int i = e * KL_THREADS + tid;
-            bool valid = i < p && col0 + c < a.ncols;
-            if (valid && a.bits) valid = !((a.bits[(size_t)col * a.words + (i >> 5)] >> (i & 31)) & 1u);
-            b[c][e] = valid ? Acol[(size_t)i * a.a_i_stride] : 0.0f;
-            if (valid) vbits[c] |= (1ull << e);
-            y[c][e] = 0.0f;
+        for (int e = 0; e < EPT4; e++) {
+            const int idx4 = e * KLT_THREADS + tid;
+            const bool valid = e < nlw && col0 + c < a.ncols;
+            b[c][e] = valid ? Ac[idx4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            y[c][e] = valid ? Yc[idx4] + tiny : f32x4{1.f, 1.f, 1.f, 1.f};
+            // (a register use right here: otherwise the wait for this load lands at its first use inside the step loop, where
+            //  it would also wait for the row prefetch issued at the top of every step)
+            asm volatile("" : "+v"(b[c][e]));
         }
     }
+    __syncthreads();
     double S[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) S[c] = 0.0;
-    if (fa.Yinit) { // y = Yt^T x was formed for all columns at once by wh_store_kernel
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const int col = (col0 + c < a.ncols) ? col0 + c : col0;
-            const float *Ycol = fa.Yinit + (size_t)col * a.a_col_stride;
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = e * KL_THREADS + tid;
-                y[c][e] = ((vbits[c] >> e) & 1ull) ? Ycol[(size_t)i * a.a_i_stride] : 0.0f;
-            }
-            for (int q = 0; q < k; q++) S[c] += xs[c][q];
-        }
-    } else
-        for (int q = 0; q < k; q++) { // y = Yt^T x, S = sum(x)
-            float w[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = e * KL_THREADS + tid;
-                w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const double xq = xs[c][q];
-                S[c] += xq;
-                const float xf = (float)xq;
-#pragma unroll
-                for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, xf, y[c][e]);
-            }
-        }
+    for (int c = 0; c < C; c++) {
+        S[c] = 0.0;
+        for (int q = 0; q < k; q++) S[c] += xs[c * k + q];
+    }
 
-    double rel[C];
     unsigned tdone[C];
-    bool run[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) rel[c] = 1.0 + a.rel_tol, tdone[c] = 0, run[c] = live[c] && a.max_iter > 0 && rel[c] > a.rel_tol;
-    int par = 0;
+    bool run[C], flag[C];
     bool any = false;
 #pragma unroll
-    for (int c = 0; c < C; c++) any = any || run[c];
-    while (any) { // block-uniform: all state that decides it is computed redundantly by every thread
+    for (int c = 0; c < C; c++) {
+        tdone[c] = 0;
+        run[c] = live[c] && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol;
+        any = any || run[c];
+    }
+    int par = 0, bufsel = 0;
+    if (any) issue(0, 0);
+    while (any) { // block-uniform: everything that decides it is computed redundantly by every thread
 #pragma unroll
-        for (int c = 0; c < C; c++)
-            if (run[c]) rel[c] = 0.0;
+        for (int c = 0; c < C; c++) flag[c] = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
+            issue((q + 1 < k) ? q + 1 : 0, bufsel ^ 1); // next row (row 0 again for a sweep that may follow)
+            kl_wait_vmcnt(nlw);                         // this wavefront's pieces of row q have landed
+            const unsigned char *rowp = kl_smem + (size_t)bufsel * rowb;
+            bufsel ^= 1;
             bool doq[C];
             bool anyq = false;
 #pragma unroll
-            for (int c = 0; c < C; c++) doq[c] = run[c] && !((mword[c] >> q) & 1ull), anyq = anyq || doq[c];
+            for (int c = 0; c < C; c++) {
+                bool m = false;
+                if (a.mask) m = (mks[c * a.mw + (q >> 6)] >> (q & 63)) & 1ull; // (LDS copy: a global load here would drain the row prefetch)
+                doq[c] = run[c] && !m;
+                anyq = anyq || doq[c];
+            }
             if (!anyq) continue;
             double xq[C];
 #pragma unroll
-            for (int c = 0; c < C; c++) xq[c] = xs[c][q]; // read BEFORE the reduction's barrier: thread 0 rewrites it after
-            float w[EPT];
+            for (int c = 0; c < C; c++) xq[c] = xs[c * k + q]; // read BEFORE the barrier: thread 0 rewrites it after
+            f32x4 acc[C][NV];
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = e * KL_THREADS + tid;
-                w[e] = (i < p) ? fa.Yf[(size_t)q * fa.ldyf + i] : 0.0f;
-            }
-            double v[NV * C];
+            for (int c = 0; c < C; c++)
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                float s0 = 0.0f, s1 = 0.0f, sw = 0.0f;
+                for (int v = 0; v < NV; v++) acc[c][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the row element of chunk e + 1 is fetched from LDS while chunk e is processed; the scheduling barrier keeps the
+            // compiler from hoisting all EPT4 fetches (and their registers) to the top of the unrolled loop
+            auto wload = [&](int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * KLT_THREADS + tid) * 16); };
+            f32x4 wcur = wload(0);
 #pragma unroll
-                for (int e = 0; e < EPT; e++) {
-                    const float we = ((vbits[c] >> e) & 1ull) ? w[e] : 0.0f;
-                    const float r = __builtin_amdgcn_rcpf(y[c][e] + tiny);
-                    if (METHOD == 4) {
-                        s0 = __builtin_fmaf(we, b[c][e] * r, s0); // Wt.row(k) * (Aj / (wh + eps)), :141
-                    } else {
-                        const float u = we * r;                   // mu, :97
-                        s0 = __builtin_fmaf(b[c][e] * u, u, s0);  // a, :98
-                        s1 = __builtin_fmaf(b[c][e], u, s1);      // b, :99
+            for (int e = 0; e < EPT4; e++) {
+                if (e < nlw) { // wave-uniform
+                    const f32x4 w = wcur;
+                    if (e + 1 < EPT4 && e + 1 < nlw) wcur = wload(e + 1);
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        f32x4 r;
+                        r[0] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][0]));
+                        r[1] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][1]));
+                        r[2] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][2]));
+                        r[3] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][3]));
+                        if (METHOD == 4) {
+                            acc[c][0] = __builtin_elementwise_fma(w, b[c][e] * r, acc[c][0]); // Wt.row(k) * (Aj / (wh + eps)), :141
+                        } else {
+                            const f32x4 u = w * r;                                             // mu, :97
+                            const f32x4 bu = b[c][e] * u;
+                            acc[c][0] = __builtin_elementwise_fma(bu, u, acc[c][0]);           // a, :98
+                            acc[c][1] = acc[c][1] + bu;                                        // b, :99
+                        }
                     }
-                    sw += we; // sumW over the same index set
                 }
-                v[NV * c] = (double)s0;
-                if (METHOD != 4) v[NV * c + 1] = (double)s1;
-                v[NV * c + NV - 1] = (double)sw;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            kl_block_sum<NV * C>(v, red, par);
-            par ^= 1;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float t = kl_wave_total((acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]));
+                    if (lane == 63) red[((par * C + c) * NV + v) * 8 + wave] = t;
+                }
+            __syncthreads();
+            float coef[C];
 #pragma unroll
             for (int c = 0; c < C; c++) {
+                coef[c] = 0.f;
                 if (!doq[c]) continue; // block-uniform
-                float coef = 0.0f;
+                double sv[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float *rr = red + ((par * C + c) * NV + v) * 8;
+                    sv[v] = (((double)rr[0] + (double)rr[1]) + ((double)rr[2] + (double)rr[3])) + (((double)rr[4] + (double)rr[5]) + ((double)rr[6] + (double)rr[7]));
+                }
+                const double sw = sws[c * k + q];
                 if (METHOD == 4) {
-                    double tmp = v[NV * c] / (v[NV * c + 1] + a.r0 * xq[c] + a.r1 * (S[c] - xq[c]) + a.r2); // :142
-                    coef = (float)((tmp - 1) * xq[c]);                                                      // :143
-                    S[c] += (tmp - 1) * xq[c];                                                              // :144
-                    if (tid == 0) xs[c][q] = xq[c] * tmp;                                                   // :145
-                    tmp = 2 * fabs(tmp - 1) / (tmp + 1);
-                    if (tmp > rel[c]) rel[c] = tmp;
+                    const double den = sw + a.r0 * xq[c] + a.r1 * (S[c] - xq[c]) + a.r2; // :142
+                    double rd = __builtin_amdgcn_rcp(den);
+                    rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
+                    const double tmp = sv[0] * rd;
+                    const double d = (tmp - 1) * xq[c]; // :143
+                    coef[c] = (float)d;
+                    S[c] += d;                          // :144
+                    if (tid == 0) xs[c * k + q] = xq[c] * tmp; // :145
+                    flag[c] = flag[c] || (2 * fabs(tmp - 1) > a.rel_tol * (tmp + 1)); // :146-147 without the division
                 } else {
-                    double aa = v[NV * c], bb = v[NV * c + 1] - v[NV * c + 2]; // b = dot(Aj, mu) - sumW(k), :99
-                    aa += a.r0;                                                // :100
-                    bb += aa * xq[c] - a.r2 - a.r1 * (S[c] - xq[c]);           // :101
-                    double tmp = bb / (aa + NNLM_TINY);                        // :102
-                    if (tmp < 0) tmp = 0;
+                    const double aa = sv[0] + a.r0;                                              // :98,100
+                    const double bb = (sv[1] - sw) + aa * xq[c] - a.r2 - a.r1 * (S[c] - xq[c]); // :99,101
+                    const double den = aa + NNLM_TINY;
+                    double rd = __builtin_amdgcn_rcp(den);
+                    rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
+                    double tmp = bb * rd; // :102
+                    if (!(tmp > 0)) tmp = 0;
                     if (tmp != xq[c]) {
-                        coef = (float)(tmp - xq[c]);
-                        const double er = 2 * fabs(xq[c] - tmp) / (tmp + xq[c] + NNLM_TINY);
-                        if (er > rel[c]) rel[c] = er;
-                        S[c] += tmp - xq[c];
-                        if (tid == 0) xs[c][q] = tmp;
+                        const double d = tmp - xq[c];
+                        coef[c] = (float)d;
+                        flag[c] = flag[c] || (2 * fabs(d) > a.rel_tol * (tmp + xq[c] + NNLM_TINY)); // :107-108
+                        S[c] += d;
+                        if (tid == 0) xs[c * k + q] = tmp;
                     }
                 }
-                if (coef != 0.0f) {
+            }
+            par ^= 1;
+            bool anyc = false;
 #pragma unroll
-                    for (int e = 0; e < EPT; e++) y[c][e] = __builtin_fmaf(coef, ((vbits[c] >> e) & 1ull) ? w[e] : 0.0f, y[c][e]); // :106, :143
+            for (int c = 0; c < C; c++) anyc = anyc || coef[c] != 0.f;
+            if (anyc) { // pass B: y += coef * w for every column of the block (coef = 0 leaves a column's state as it is)
+                f32x4 wb = wload(0);
+#pragma unroll
+                for (int e = 0; e < EPT4; e++) {
+                    if (e < nlw) { // wave-uniform
+                        const f32x4 w = wb;
+                        if (e + 1 < EPT4 && e + 1 < nlw) wb = wload(e + 1);
+#pragma unroll
+                        for (int c = 0; c < C; c++) y[c][e] = __builtin_elementwise_fma(f32x4{coef[c], coef[c], coef[c], coef[c]}, w, y[c][e]); // :106, :143
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -346,20 +469,20 @@ __global__ __launch_bounds__(KL_THREADS) void kl_fast_kernel(const KlFastArgs fa
         for (int c = 0; c < C; c++) {
             if (run[c]) {
                 tdone[c]++;
-                run[c] = tdone[c] < a.max_iter && rel[c] > a.rel_tol;
+                run[c] = tdone[c] < a.max_iter && flag[c];
             }
             any = any || run[c];
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the row requested for a sweep that did not follow
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        const int col = col0 + c;
-        if (col < a.ncols && tid < k) {
-            const double xv = xs[c][tid];
-            a.Xout[(size_t)tid * a.ldx + col] = xv;
-            if (a.op_mode == 1) ((float *)a.op)[(size_t)tid * a.op_ld + col] = (float)xv;
-            else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + tid] = (float)xv;
+    for (int e = tid; e < C * k; e += KLT_THREADS) {
+        const int c = e / k, q = e - c * k, col = col0 + c;
+        if (col < a.ncols) {
+            const double xv = xs[e];
+            a.Xout[(size_t)q * a.ldx + col] = xv;
+            if (a.op_mode == 1) ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
+            else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
     }
     if (tid == 0) {
@@ -368,4 +491,163 @@ __global__ __launch_bounds__(KL_THREADS) void kl_fast_kernel(const KlFastArgs fa
         for (int c = 0; c < C; c++) tot += tdone[c];
         if (tot) atomicAdd(a.sweeps, tot);
     }
+}
+
+// sumw[q] = sum_i Y[q][i], i < p (fp64, from the master): sumW of src/update_with_missing.cpp:27
+__global__ __launch_bounds__(256) void kl_sumw_kernel(const double *__restrict__ Y, int ldy, int p, double *__restrict__ sumw)
+{
+    __shared__ double part[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < p; i += 256) s += Y[(size_t)q * ldy + i];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) part[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) sumw[q] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// Per-column row sums over the non-missing entries (src/update_with_missing.cpp:122,130) from the CSR row lists of
+// k_missing.h (the listed rows are the missing ones when meta's top bit is set: sum = full - listed).  One wavefront per
+// column, lane = coordinate (chunks of 64), Yrow [p][KP] row-major.
+__global__ __launch_bounds__(256) void kl_sumw_cols_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
+                                                           const double *__restrict__ Yrow, int KP, int k, const double *__restrict__ sumw_full,
+                                                           double *__restrict__ out, int ldsw, int ncols)
+{
+    const int lane = threadIdx.x & 63, col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= ncols) return;
+    const uint32_t mt = meta[col];
+    const int len = (int)(mt & 0x7FFFFFFFu);
+    const bool complement = (mt >> 31) != 0;
+    const int *rows = idx + ptr[col];
+    for (int q0 = 0; q0 < k; q0 += 64) {
+        const int q = q0 + lane;
+        double s = 0.0;
+        if (q < k)
+            for (int r = 0; r < len; r++) s += Yrow[(size_t)rows[r] * KP + q];
+        if (q < k) out[(size_t)col * ldsw + q] = complement ? sumw_full[q] - s : s;
+    }
+}
+
+// ==================================================================================================================
+// kl_stream_kernel -- the KL solvers without size limits (any contraction length, any rank, both precisions): what runs
+// when the register-resident kernels do not fit (contraction longer than they hold, rank beyond a 64-bit mask word, LDS).
+// One 256-thread block per column; the state vector y and a contiguous copy of the data column live in a global scratch
+// buffer St [ncols][2][ldst] (y, then b) and are streamed once per coordinate step: the pending rank-1 refresh of step
+// q-1 is applied while the sums of step q are formed.  Same arithmetic as kl_update_kernel (T = double: the reference's).
+template <typename T, int METHOD>
+__global__ __launch_bounds__(256) void kl_stream_kernel(const KlArgs a, int mw, T *__restrict__ St, size_t ldst)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kls_smem[];
+    double *xs = (double *)kls_smem; // [k]
+    double *red = xs + a.k;          // [2][3][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = blockIdx.x, k = a.k, p = a.p;
+    T *ys = St + (size_t)col * 2 * ldst, *bs = ys + ldst;
+    const uint32_t *bits = a.bits ? a.bits + (size_t)col * a.words : nullptr;
+
+    bool skipcol = false;
+    if (a.mask) {
+        skipcol = true;
+        for (int w = 0; w < mw; w++) {
+            const int nb = (k - 64 * w >= 64) ? 64 : k - 64 * w;
+            const unsigned long long km = (nb >= 64) ? ~0ull : ((1ull << nb) - 1ull);
+            skipcol = skipcol && ((a.mask[(size_t)col * mw + w] & km) == km);
+        }
+    }
+    for (int q = tid; q < k; q += 256) xs[q] = a.X[(size_t)q * a.ldx + col];
+    __syncthreads();
+    double S = 0.0;
+    for (int q = 0; q < k; q++) S += xs[q];
+    auto valid_at = [&](int i) { return !(bits && ((bits[i >> 5] >> (i & 31)) & 1u)); };
+    if (!skipcol && a.max_iter > 0) { // y = Yt^T x over the finite entries; contiguous copy of the data column
+        const T *Acol = (const T *)a.A + (size_t)col * a.a_col_stride;
+        for (int i = tid; i < p; i += 256) {
+            const bool v = valid_at(i);
+            double yv = 0.0;
+            if (v)
+                for (int q = 0; q < k; q++) yv = __builtin_fma(a.Y[(size_t)q * a.ldy + i], xs[q], yv);
+            ys[i] = (T)yv;
+            bs[i] = v ? Acol[(size_t)i * a.a_i_stride] : (T)0;
+        }
+    }
+    double rel = 1.0 + a.rel_tol;
+    unsigned t = 0;
+    int par = 0, qprev = -1;
+    double cprev = 0.0;
+    for (; !skipcol && t < a.max_iter && rel > a.rel_tol; t++) {
+        rel = 0.0;
+        for (int q = 0; q < k; q++) {
+            if (a.mask && ((a.mask[(size_t)col * mw + (q >> 6)] >> (q & 63)) & 1ull)) continue;
+            const double xq = xs[q];
+            double v[3] = {0.0, 0.0, 0.0};
+            for (int i = tid; i < p; i += 256) {
+                const bool ok = valid_at(i);
+                double yv = (double)ys[i];
+                if (cprev != 0.0) { // the refresh step qprev owes this entry (:106, :143)
+                    if (ok) yv = __builtin_fma(cprev, a.Y[(size_t)qprev * a.ldy + i], yv);
+                    if (sizeof(T) == 4) yv = (double)(float)yv;
+                    ys[i] = (T)yv;
+                }
+                const double w = ok ? a.Y[(size_t)q * a.ldy + i] : 0.0;
+                const double bv = (double)bs[i];
+                if (METHOD == 4) {
+                    v[0] += w * (bv / (yv + NNLM_TINY));
+                } else {
+                    const double u = w / (yv + NNLM_TINY);
+                    v[0] += bv * (u * u);
+                    v[1] += bv * u;
+                }
+                v[2] += w;
+            }
+            cprev = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                v[c] = wave_sum(v[c]);
+                if (lane == 0) red[(par * 3 + c) * 4 + wave] = v[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double *r = red + (par * 3 + c) * 4;
+                v[c] = (r[0] + r[1]) + (r[2] + r[3]);
+            }
+            par ^= 1;
+            if (METHOD == 4) {
+                double tmp = v[0] / (v[2] + a.r0 * xq + a.r1 * (S - xq) + a.r2);
+                cprev = (tmp - 1) * xq;
+                S += (tmp - 1) * xq;
+                if (tid == 0) xs[q] = xq * tmp;
+                tmp = 2 * fabs(tmp - 1) / (tmp + 1);
+                if (tmp > rel) rel = tmp;
+            } else {
+                double aa = v[0], bb = v[1] - v[2];
+                aa += a.r0;
+                bb += aa * xq - a.r2 - a.r1 * (S - xq);
+                double tmp = bb / (aa + NNLM_TINY);
+                if (tmp < 0) tmp = 0;
+                if (tmp != xq) {
+                    cprev = tmp - xq;
+                    const double er = 2 * fabs(xq - tmp) / (tmp + xq + NNLM_TINY);
+                    if (er > rel) rel = er;
+                    S += tmp - xq;
+                    if (tid == 0) xs[q] = tmp;
+                }
+            }
+            qprev = q;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int q = tid; q < k; q += 256) {
+        const double xv = xs[q];
+        a.Xout[(size_t)q * a.ldx + col] = xv;
+        if (a.op_mode == 1) {
+            if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
+            else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
+        } else if (a.op_mode == 2) {
+            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
+            else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
+        }
+    }
+    if (tid == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }

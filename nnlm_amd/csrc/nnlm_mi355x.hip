@@ -12,6 +12,7 @@
 #include "../../include/nnlm_mi355x.h"
 #include "common.h"
 #include "k_errors.h"
+#include "k_generic.h"
 #include "k_gram.h"
 #include "k_kl.h"
 #include "k_missing.h"
@@ -69,8 +70,14 @@ struct nnlm_handle {
     void *Wopb[2] = {nullptr, nullptr};           // speculative half-step can be dropped and the error block can read W_i
     int wcur = 0;
     float *Hkq = nullptr;                         // fp32 [KP][mpad] copy of H, refreshed by nnlm_errors (f32 mode)
-    unsigned long long *Wmask = nullptr, *Hmask = nullptr; // per column bitmask, or null
+    unsigned long long *Wmask = nullptr, *Hmask = nullptr; // [npad][MW], [mpad][MW]: bit q of a column's words = entry (q, col) is masked
     bool has_wmask = false, has_hmask = false;
+    int MW = 1;                                   // 64-bit mask words per column = ceil(k / 64)
+    void *AT = nullptr;                           // T [npad][mpad]: contraction-contiguous copy of A for the W half-step of the paths that
+                                                  // stream it with the TN kernels (rank > 64) or per column (KL, F32 mode); made on first use
+    double *klsw = nullptr, *klsw_cols = nullptr; // KL: row sums of the fixed factor [KP] / per column over its non-missing entries [cols][KP]
+    void *klst = nullptr;                         // kl_stream_kernel: [cols][2][ld] state vectors + data columns
+    size_t klst_bytes = 0;
 
     // workspaces
     double *Cx = nullptr;
@@ -314,6 +321,12 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Cx);
     hipFree(h->What);
     h->What = nullptr;
+    hipFree(h->klsw);
+    hipFree(h->klsw_cols);
+    hipFree(h->klst);
+    h->klsw = h->klsw_cols = nullptr;
+    h->klst = nullptr;
+    h->klst_bytes = 0;
     hipFree(h->Y16);
     hipFree(h->W16c);
     hipFree(h->H16c);
@@ -347,6 +360,8 @@ static void free_matrix(nnlm_handle *h)
         h->na_idx[o] = nullptr;
     }
     hipFree(h->A);
+    hipFree(h->AT);
+    h->AT = nullptr;
     hipFree(h->A16);
     hipFree(h->A16T);
     h->A16 = h->A16T = nullptr;
@@ -537,6 +552,9 @@ static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
     } else if (h->x16) { // split-fp16: the TN kernel on the transposed copy, tiles of 128 rows of A, stages of 64 columns
         stages_total = h->mpad / 64;
         tiles_x = h->npad / XPROD_TN_BJ;
+    } else if (h->k > NNLM_KQ_MAX) { // rank > 64: the TN kernel on the transposed copy AT (launch_xprod_generic)
+        stages_total = h->mpad / (XPROD_ROWB / (int)esize(h));
+        tiles_x = h->npad / XPROD_TN_BJ;
     } else {
         stages_total = h->mpad / XPROD_NT_ROWS;
         const int BI = 64 * (16 / (int)esize(h));
@@ -555,18 +573,25 @@ static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
     return p;
 }
 
-static void pack_mask_cols(const int *mask, int k, int ncols, bool transposed_input, int ld_in, std::vector<unsigned long long> &out, int npadded)
+// contraction elements one stage of the cross product of half-step `which` covers (the granularity of the multi-GPU split)
+static int stage_elems(const nnlm_handle *h, int which)
 {
-    // transposed_input: mask is ncols x k column-major (Wm, n x k); else k x ncols column-major (Hm)
-    out.assign(npadded, 0ull);
-    for (int c = 0; c < ncols; c++) {
-        unsigned long long w = 0;
+    if (which == 1) return XPROD_ROWB / (int)esize(h);
+    if (h->x16) return 64;
+    if (h->k > NNLM_KQ_MAX) return XPROD_ROWB / (int)esize(h);
+    return XPROD_NT_ROWS;
+}
+
+static void pack_mask_cols(const int *mask, int k, int ncols, bool transposed_input, int ld_in, std::vector<unsigned long long> &out, int npadded,
+                           int mw)
+{
+    // transposed_input: mask is ncols x k column-major (Wm, n x k); else k x ncols column-major (Hm); mw words per column
+    out.assign((size_t)npadded * mw, 0ull);
+    for (int c = 0; c < ncols; c++)
         for (int q = 0; q < k; q++) {
             const int v = transposed_input ? mask[(size_t)q * ld_in + c] : mask[(size_t)c * ld_in + q];
-            if (v != 0) w |= (1ull << q);
+            if (v != 0) out[(size_t)c * mw + (q >> 6)] |= (1ull << (q & 63));
         }
-        out[c] = w;
-    }
 }
 
 extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, const double *H, const int *Wm, const int *Hm)
@@ -574,15 +599,16 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     if (!h || !h->A) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: set the matrix first");
     const int k = (int)k_;
     if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
-    if (k > NNLM_KQ_MAX) return fail(h, NNLM_ERR_UNSUPPORTED, "nnlm_set_factors: rank k=%d > %d is not supported by this build", k, NNLM_KQ_MAX);
+    if (k > NNLM_KQ_MAX && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "nnlm_set_factors: rank k=%d > %d is not sharded across GPUs in this build", k, NNLM_KQ_MAX);
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
     if (k != h->k) {
         free_factors(h);
         h->k = k;
-        h->NKQ = (k + 15) / 16;
+        h->NKQ = (k + 15) / 16; // > 4 beyond rank 64: the generic kernels of k_generic.h take over
         h->KP = 16 * h->NKQ;
         h->KP8 = round_up_i(k, 8);
+        h->MW = (k + 63) / 64;
         const size_t es = esize(h);
         for (int i = 0; i < 2; i++) {
             HIPCHK(h, hipMalloc(&h->W64b[i], (size_t)h->KP * h->npad * 8));
@@ -596,8 +622,8 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
         HIPCHK(h, hipMalloc(&h->H64, (size_t)h->KP * h->mpad * 8));
         HIPCHK(h, hipMalloc(&h->Hop, (size_t)h->mpad * h->KP * es + 4096));
         if (h->prec == NNLM_PREC_F32) HIPCHK(h, hipMalloc(&h->Hkq, (size_t)h->KP * h->mpad * sizeof(float)));
-        HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * 8));
-        HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * 8));
+        HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * h->MW * 8));
+        HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * h->MW * 8));
         // split-K slabs: sized for the worst case over ranks (nranks = 1 gives the largest S)
         const HalfPlan ph = plan_half(h, 1, 0, 1), pw = plan_half(h, 0, 0, 1);
         size_t eh = (size_t)ph.S * h->KP * h->mpad, ew = (size_t)pw.S * h->KP * h->npad;
@@ -648,12 +674,12 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     h->has_wmask = Wm != nullptr;
     h->has_hmask = Hm != nullptr;
     if (Wm) {
-        pack_mask_cols(Wm, k, n, true, n, mk, npad);
-        HIPCHK(h, hipMemcpy(h->Wmask, mk.data(), (size_t)npad * 8, hipMemcpyHostToDevice));
+        pack_mask_cols(Wm, k, n, true, n, mk, npad, h->MW);
+        HIPCHK(h, hipMemcpy(h->Wmask, mk.data(), (size_t)npad * h->MW * 8, hipMemcpyHostToDevice));
     }
     if (Hm) {
-        pack_mask_cols(Hm, k, m, false, k, mk, mpad);
-        HIPCHK(h, hipMemcpy(h->Hmask, mk.data(), (size_t)mpad * 8, hipMemcpyHostToDevice));
+        pack_mask_cols(Hm, k, m, false, k, mk, mpad, h->MW);
+        HIPCHK(h, hipMemcpy(h->Hmask, mk.data(), (size_t)mpad * h->MW * 8, hipMemcpyHostToDevice));
     }
     return NNLM_OK;
 }
@@ -732,15 +758,18 @@ static void launch_xprod_nkq(nnlm_handle *h, int which, const HalfPlan &p)
 
 // Split-fp16 cross product (k_xprod16.h): split copy of the fixed factor scaled by its own power of two, then the
 // A-streaming kernel on A16 (H half-step) or A16T (W half-step: the transposed copy makes it the same "TN" kernel).
+// Y16 / Cx / slab_stride: rows [q0, q0 + 16 NKQ) of the split copy and of the slabs when the rank exceeds 64 (NULL / 0: all of them)
 template <int NKQ>
-static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int ldy, int ldc, const HalfPlan &p)
+static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int ldy, int ldc, const HalfPlan &p, const uint32_t *Y16 = nullptr,
+                             double *Cx = nullptr, size_t slab_stride = 0)
 {
     const int KP = 16 * NKQ;
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(KP);
     hipFuncSetAttribute((const void *)xprod16_tn_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16, lda, h->Y16, ldy, h->Cx, ldc, (size_t)KP * ldc, p.stage_begin,
-                                                                    p.stage_end, p.sps, h->scal_exp);
+    xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16, lda, Y16 ? Y16 : h->Y16, ldy, Cx ? Cx : h->Cx, ldc,
+                                                                    slab_stride ? slab_stride : (size_t)KP * ldc, p.stage_begin, p.stage_end, p.sps,
+                                                                    h->scal_exp);
 }
 // split copy of the fixed factor, scaled by its own power of two (two small kernels, outside the cross product's timing
 // scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
@@ -805,10 +834,100 @@ static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
     }
 }
 
+// ---- rank > 64 (k_generic.h): the same A-streaming kernels, launched once per 64 rows of the fixed factor --------------
+static bool generic_rank(const nnlm_handle *h) { return h->k > NNLM_KQ_MAX; }
+
+// contraction-contiguous copy of A ([npad][mpad], element type of the mode), made once per matrix
+static int ensure_AT(nnlm_handle *h)
+{
+    if (h->AT) return NNLM_OK;
+    HIPCHK(h, hipMalloc(&h->AT, (size_t)h->npad * h->mpad * esize(h) + 4096));
+    dim3 grid(h->npad / 64, h->mpad / 64);
+    if (h->prec == NNLM_PREC_F64) transpose_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, (double *)h->AT, h->mpad);
+    else transpose_kernel<float><<<grid, 256, 0, h->stream>>>((const float *)h->A, h->npad, (float *)h->AT, h->mpad);
+    HIPCHK(h, hipGetLastError());
+    return NNLM_OK;
+}
+
+template <typename T, int NKQ>
+static void launch_xprod_tn_rows(nnlm_handle *h, const T *Amat, int lda, const T *Y, int ldy, double *C, int ldc, size_t slab_stride, const HalfPlan &p)
+{
+    dim3 grid(p.tiles_x, p.S);
+    const int lds = xprod_tn_lds_bytes(16 * NKQ);
+    hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    xprod_tn_kernel<T, NKQ, 0><<<grid, XPROD_THREADS, lds, h->stream>>>(Amat, lda, Y, ldy, C, ldc, slab_stride, p.stage_begin, p.stage_end, p.sps);
+}
+
+template <typename T>
+static int launch_xprod_generic_t(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    const int KP = h->KP;
+    const T *Amat;
+    const T *Y;
+    int lda, ldy, ldc;
+    if (which == 1) {
+        Amat = (const T *)h->A; lda = h->npad; Y = (const T *)h->Wop; ldy = h->npad; ldc = h->mpad;
+    } else {
+        int rc = ensure_AT(h);
+        if (rc != NNLM_OK) return rc;
+        Amat = (const T *)h->AT; lda = h->mpad; ldy = h->mpad; ldc = h->npad;
+        if (h->prec == NNLM_PREC_F64) Y = (const T *)h->H64;
+        else { // fp32 [KP][mpad] copy of H
+            const size_t cnt = (size_t)KP * h->mpad;
+            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
+            Y = (const T *)h->Hkq;
+        }
+    }
+    const size_t slab = (size_t)KP * ldc;
+    for (int q0 = 0; q0 < KP; q0 += 64) {
+        const int nk = (KP - q0 >= 64) ? 4 : (KP - q0) / 16;
+        const T *Yq = Y + (size_t)q0 * ldy;
+        double *Cq = h->Cx + (size_t)q0 * ldc;
+        switch (nk) {
+        case 1: launch_xprod_tn_rows<T, 1>(h, Amat, lda, Yq, ldy, Cq, ldc, slab, p); break;
+        case 2: launch_xprod_tn_rows<T, 2>(h, Amat, lda, Yq, ldy, Cq, ldc, slab, p); break;
+        case 3: launch_xprod_tn_rows<T, 3>(h, Amat, lda, Yq, ldy, Cq, ldc, slab, p); break;
+        default: launch_xprod_tn_rows<T, 4>(h, Amat, lda, Yq, ldy, Cq, ldc, slab, p); break;
+        }
+    }
+    return NNLM_OK;
+}
+
+static int launch_xprod_generic(nnlm_handle *h, int which, const HalfPlan &p)
+{
+    if (h->x16) { // split-fp16 copies A16 / A16T exist: the split copy of the factor (prepare_factor16) covers all KP rows
+        const int KP = h->KP;
+        const int ldm = (which == 1) ? h->npad : h->mpad, ldc = (which == 1) ? h->mpad : h->npad;
+        const uint32_t *A16 = (which == 1) ? h->A16 : h->A16T;
+        const size_t slab = (size_t)KP * ldc;
+        for (int q0 = 0; q0 < KP; q0 += 64) {
+            const int nk = (KP - q0 >= 64) ? 4 : (KP - q0) / 16;
+            const uint32_t *Yq = h->Y16 + (size_t)q0 * ldm;
+            double *Cq = h->Cx + (size_t)q0 * ldc;
+            switch (nk) {
+            case 1: launch_xprod16_m<1>(h, A16, ldm, ldm, ldc, p, Yq, Cq, slab); break;
+            case 2: launch_xprod16_m<2>(h, A16, ldm, ldm, ldc, p, Yq, Cq, slab); break;
+            case 3: launch_xprod16_m<3>(h, A16, ldm, ldm, ldc, p, Yq, Cq, slab); break;
+            default: launch_xprod16_m<4>(h, A16, ldm, ldm, ldc, p, Yq, Cq, slab); break;
+            }
+        }
+        return NNLM_OK;
+    }
+    if (h->prec == NNLM_PREC_F64) return launch_xprod_generic_t<double>(h, which, p);
+    return launch_xprod_generic_t<float>(h, which, p);
+}
+
 static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, int c_end, int *nslabs)
 {
     int nb = (c_end - c_begin + GRAM_COLS_PER_BLOCK - 1) / GRAM_COLS_PER_BLOCK;
     if (nb < 1) nb = 1;
+    if (generic_rank(h)) {
+        dim3 grid(nb, h->NKQ * (h->NKQ + 1) / 2);
+        gram_partial_generic_kernel<<<grid, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->NKQ, h->gslabs);
+        gram_reduce_kernel<<<(h->KP * h->KP + 255) / 256, 256, 0, h->stream_g>>>(h->gslabs, nb, h->KP, h->Graw);
+        *nslabs = nb;
+        return;
+    }
     switch (h->NKQ) {
     case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
     case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
@@ -918,8 +1037,28 @@ static void launch_sweep_wg(nnlm_handle *h, const SweepArgs &a, int nb)
     }
 }
 
-static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
+// rank > 64: one wavefront per column, coordinates in LDS (k_generic.h); g_stride != 0: per-column Grams (missing values)
+static int launch_sweep_generic(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
 {
+    const int ncols = a.ncols - a.col0;
+    if (ncols <= 0) return NNLM_OK;
+    const bool g_in_lds = g_stride == 0 && sweep_generic_lds_bytes(a.k, a.KPg, true) <= (size_t)160 * 1024;
+    const size_t lds = sweep_generic_lds_bytes(a.k, a.KPg, g_in_lds);
+    if (lds > (size_t)160 * 1024) return fail(h, NNLM_ERR_UNSUPPORTED, "rank %d needs %zu bytes of LDS per workgroup (limit 160 KiB)", a.k, lds);
+    const int nb = (ncols + 3) / 4;
+    if (method == 1) {
+        hipFuncSetAttribute((const void *)sweep_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        sweep_generic_kernel<1><<<nb, 256, lds, h->stream>>>(a, g_stride, h->MW, g_in_lds ? 1 : 0);
+    } else {
+        hipFuncSetAttribute((const void *)sweep_generic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        sweep_generic_kernel<2><<<nb, 256, lds, h->stream>>>(a, g_stride, h->MW, g_in_lds ? 1 : 0);
+    }
+    return NNLM_OK;
+}
+
+static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
+{
+    if (generic_rank(h)) return launch_sweep_generic(h, method, a, 0);
     if (method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
         const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
         const bool hm = a.mask != nullptr, fast = sweep_fast(h);
@@ -939,7 +1078,7 @@ static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
         default: NNLM_WG_SWEEP(4) break;
         }
 #undef NNLM_WG_SWEEP
-        return;
+        return NNLM_OK;
     }
     if (method == 1 && use_mfma_sweep()) {
         const int nb = (a.ncols + 63) / 64;
@@ -954,13 +1093,14 @@ static void launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
         default: NNLM_MFMA_SWEEP(4) break;
         }
 #undef NNLM_MFMA_SWEEP
-        return;
+        return NNLM_OK;
     }
     const int L = sweep_lanes_per_column(a.ncols);
     const int rneed = (h->k + L - 1) / L;
     if (L == 4) launch_sweep_l<2, 4>((rneed + 1) / 2, method, a, h->stream);      // R = 2..16, k <= 64
     else if (L == 2) launch_sweep_l<4, 2>((rneed + 3) / 4, method, a, h->stream); // R = 4..32
     else launch_sweep_l<8, 1>((rneed + 7) / 8, method, a, h->stream);             // R = 8..64
+    return NNLM_OK;
 }
 
 template <typename T, int EPT>
@@ -986,37 +1126,62 @@ static void launch_kl(int method, const KlArgs &a, hipStream_t s)
     else launch_kl_m<T, 64>(method, a, s);
 }
 
-// F32 mode: kl_fast_kernel (fp32 state, v_rcp_f32 quotients, fp32 rows of the fixed factor, two columns per block);
-// NNLM_KL_FAST=0 keeps the fp64 kernel for A/B runs.
-template <int EPT, int C>
-static void launch_kl_fast_m(int method, const KlFastArgs &fa, hipStream_t s)
+// F32 mode: kl_tile_kernel (k_kl.h).  EPT4 = float4 chunks of the contraction per thread, C = columns per workgroup
+// (C * EPT4 * 8 state registers per thread); NNLM_KL_TILE=0 forces kl_stream_kernel for A/B runs.
+template <int EPT4, int C>
+static void launch_kl_tile_m(int method, const KlTileArgs &ta, int nb, size_t lds, hipStream_t s)
 {
-    const int nb = (fa.a.ncols + C - 1) / C;
-    if (method == 3) kl_fast_kernel<EPT, 3, C><<<nb, KL_THREADS, 0, s>>>(fa);
-    else kl_fast_kernel<EPT, 4, C><<<nb, KL_THREADS, 0, s>>>(fa);
-}
-static void launch_kl_fast(int method, const KlFastArgs &fa, hipStream_t s)
-{
-    const int ept = (fa.a.p + KL_THREADS - 1) / KL_THREADS;
-    if (ept <= 1) launch_kl_fast_m<1, 2>(method, fa, s);
-    else if (ept <= 2) launch_kl_fast_m<2, 2>(method, fa, s);
-    else if (ept <= 4) launch_kl_fast_m<4, 2>(method, fa, s);
-    else if (ept <= 8) launch_kl_fast_m<8, 2>(method, fa, s);
-    else if (ept <= 16) launch_kl_fast_m<16, 2>(method, fa, s);
-    else if (ept <= 24) launch_kl_fast_m<24, 2>(method, fa, s);
-    else if (ept <= 32) launch_kl_fast_m<32, 2>(method, fa, s);
-    else if (ept <= 40) launch_kl_fast_m<40, 2>(method, fa, s);
-    else if (ept <= 48) launch_kl_fast_m<48, 1>(method, fa, s);
-    else launch_kl_fast_m<64, 1>(method, fa, s);
-}
-static bool use_kl_fast()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NNLM_KL_FAST");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+    if (method == 3) {
+        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_tile_kernel<EPT4, C, 3><<<nb, KLT_THREADS, lds, s>>>(ta);
+    } else {
+        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_tile_kernel<EPT4, C, 4><<<nb, KLT_THREADS, lds, s>>>(ta);
     }
-    return v == 1;
+}
+static int kl_tile_cols(int ept4) { return ept4 <= 2 ? 8 : (ept4 <= 5 ? 4 : 2); }
+static int kl_tile_ept4(int p)
+{
+    const int e = (kl_tile_p4(p) + KLT_THREADS - 1) / KLT_THREADS;
+    const int steps[8] = {1, 2, 3, 4, 5, 6, 8, 10};
+    for (int i = 0; i < 8; i++)
+        if (e <= steps[i]) return steps[i];
+    return 0; // contraction too long for the register-resident kernel
+}
+static bool kl_tile_fits(int p, int k, int mw_masked)
+{
+    static int on = getenv("NNLM_KL_TILE") ? atoi(getenv("NNLM_KL_TILE")) : 1;
+    const int e = kl_tile_ept4(p);
+    return on && e > 0 && kl_tile_lds_bytes(p, k, kl_tile_cols(e), mw_masked) <= (size_t)160 * 1024 && 2 * round_up_i(k, 2) * ERRF_TILE * 4 <= 160 * 1024;
+}
+static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
+{
+    const int e = kl_tile_ept4(ta.p), C = kl_tile_cols(e);
+    const int nb = (ta.ncols + C - 1) / C;
+    const size_t lds = kl_tile_lds_bytes(ta.p, ta.k, C, ta.mask ? ta.mw : 0);
+    switch (e) {
+    case 1: launch_kl_tile_m<1, 8>(method, ta, nb, lds, s); break;
+    case 2: launch_kl_tile_m<2, 8>(method, ta, nb, lds, s); break;
+    case 3: launch_kl_tile_m<3, 4>(method, ta, nb, lds, s); break;
+    case 4: launch_kl_tile_m<4, 4>(method, ta, nb, lds, s); break;
+    case 5: launch_kl_tile_m<5, 4>(method, ta, nb, lds, s); break;
+    case 6: launch_kl_tile_m<6, 2>(method, ta, nb, lds, s); break;
+    case 8: launch_kl_tile_m<8, 2>(method, ta, nb, lds, s); break;
+    default: launch_kl_tile_m<10, 2>(method, ta, nb, lds, s); break;
+    }
+}
+
+template <typename T>
+static void launch_kl_stream(int method, const KlArgs &a, int mw, void *st, size_t ldst, hipStream_t s)
+{
+    const size_t lds = (size_t)(a.k + 24) * 8;
+    if (method == 3) {
+        hipFuncSetAttribute((const void *)kl_stream_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_stream_kernel<T, 3><<<a.ncols, 256, lds, s>>>(a, mw, (T *)st, ldst);
+    } else {
+        hipFuncSetAttribute((const void *)kl_stream_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_stream_kernel<T, 4><<<a.ncols, 256, lds, s>>>(a, mw, (T *)st, ldst);
+    }
 }
 
 template <int NKQ>
@@ -1073,6 +1238,13 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
 static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols)
 {
     static int use_mfma = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "valu") == 0) ? 0 : 1;
+    if (generic_rank(h)) { // rank > 64: k_generic.h
+        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
+        if (rc != NNLM_OK) return rc;
+        const int lds = 16 * h->KP * 8;
+        na_gram_generic_kernel<<<ncols, 256, lds, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->Graw, h->Gcols);
+        return NNLM_OK;
+    }
     if (use_mfma) {
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
@@ -1103,6 +1275,8 @@ static void swap_w(nnlm_handle *h)
     h->Wop = h->Wopb[h->wcur];
 }
 
+static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols);
+
 static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
                         bool speculative)
 {
@@ -1132,37 +1306,82 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         a.mask = h->has_wmask ? h->Wmask : nullptr;
         a.op = h->Wopb[h->wcur ^ 1]; a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1; a.op_ld = h->npad;
     }
-    if (a.p > KL_MAX_P) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods support a contraction length up to %d (got %d)", KL_MAX_P, a.p);
-    {
-        ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
-        if (h->prec == NNLM_PREC_F64) launch_kl<double>(method, a, h->stream);
-        else if (use_kl_fast()) {
-            KlFastArgs fa;
-            fa.a = a;
-            const size_t cnt = (size_t)h->KP * h->mpad; // [KP][mpad] fp32 copy of H (also used by the error block)
-            factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
-            if (which == 1) {
-                fa.Yf = (const float *)h->Wop; // the TN operand copy of W: [KP][npad]
-                fa.ldyf = h->npad;
-            } else {
-                fa.Yf = h->Hkq;
-                fa.ldyf = h->mpad;
-            }
-            // starting state vectors y = Yt^T x of all columns as ONE GEMM (W^T H in the layout of A) instead of k passes
-            // over the fixed factor per column; NNLM_KL_INIT=rows keeps the per-column passes
-            static int gemm_init = (getenv("NNLM_KL_INIT") && strcmp(getenv("NNLM_KL_INIT"), "rows") == 0) ? 0 : 1;
-            fa.Yinit = nullptr;
-            if (gemm_init) {
-                if (!h->What) HIPCHK(h, hipMalloc(&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096));
-                const int k2 = round_up_i(h->k, 2);
-                const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
-                hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
-                wh_store_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad);
-                fa.Yinit = h->What;
-            }
-            launch_kl_fast(method, fa, h->stream);
-        } else launch_kl<float>(method, a, h->stream);
+    const int ld_con = (which == 1) ? h->npad : h->mpad; // padded contraction length
+    ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
+    if (h->prec == NNLM_PREC_F32 && kl_tile_fits(a.p, h->k, a.mask ? h->MW : 0)) {
+        // ---- fp32-operand mode: register-resident state, rows of the fixed factor staged through LDS (kl_tile_kernel) ----
+        KlTileArgs ta;
+        const size_t cnt = (size_t)h->KP * h->mpad; // fp32 [KP][mpad] copy of H (fixed factor of the W half-step, operand of the GEMM below)
+        factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
+        if (!h->What) HIPCHK(h, hipMalloc(&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096));
+        if (!h->klsw) HIPCHK(h, hipMalloc(&h->klsw, (size_t)h->KP * 8));
+        // starting state vectors y = Yt^T x of ALL columns as one GEMM, in the layout the solver reads: [column][contraction]
+        const int k2 = round_up_i(h->k, 2);
+        const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
+        hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (which == 1) {
+            dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
+            wh_store_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad);
+            ta.Adata = (const float *)h->A;
+            ta.Yf = (const float *)h->Wop;
+        } else { // roles swapped: What^T [row of A][column of A], next to the transposed fp32 copy of A
+            int rc = ensure_AT(h);
+            if (rc != NNLM_OK) return rc;
+            dim3 grid(h->mpad / ERRF_TILE, h->npad / ERRF_TILE);
+            wh_store_kernel<<<grid, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop, h->npad, k2, h->What, h->mpad);
+            ta.Adata = (const float *)h->AT;
+            ta.Yf = h->Hkq;
+        }
+        ta.lda = (size_t)ld_con;
+        ta.Yinit = h->What;
+        ta.ldyf = ld_con;
+        ta.p = a.p;
+        ta.ncols = a.ncols;
+        ta.k = h->k;
+        ta.X = a.X;
+        ta.Xout = a.Xout;
+        ta.ldx = a.ldx;
+        kl_sumw_kernel<<<h->k, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->klsw);
+        ta.sumw = h->klsw;
+        ta.sumw_cols = nullptr;
+        ta.ldsw = h->KP;
+        if (h->any_missing) { // row sums over each column's non-missing entries (src/update_with_missing.cpp:122,130)
+            const int big = h->npad > h->mpad ? h->npad : h->mpad;
+            if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
+            if (!h->klsw_cols) HIPCHK(h, hipMalloc(&h->klsw_cols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * 8));
+            int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, a.ncols);
+            if (rc != NNLM_OK) return rc;
+            factor_rows_kernel<<<(a.p + 255) / 256, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->KP, h->Yrow);
+            kl_sumw_cols_kernel<<<(a.ncols + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
+                                                                         h->klsw, h->klsw_cols, h->KP, a.ncols);
+            ta.sumw_cols = h->klsw_cols;
+        }
+        ta.r0 = reg[0];
+        ta.r1 = reg[1];
+        ta.r2 = reg[2];
+        ta.mask = a.mask;
+        ta.mw = h->MW;
+        ta.max_iter = inner_max_iter;
+        ta.rel_tol = inner_rel_tol;
+        ta.op = a.op;
+        ta.op_mode = a.op_mode;
+        ta.op_ld = a.op_ld;
+        ta.sweeps = a.sweeps;
+        launch_kl_tile(method, ta, h->stream);
+    } else if (h->prec == NNLM_PREC_F64 && !generic_rank(h) && a.p <= KL_MAX_P) {
+        launch_kl<double>(method, a, h->stream); // strict mode, state in registers
+    } else {
+        // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel) ----
+        const size_t need = (size_t)a.ncols * 2 * ld_con * esize(h);
+        if (h->klst_bytes < need) {
+            hipFree(h->klst);
+            h->klst = nullptr;
+            h->klst_bytes = 0;
+            HIPCHK(h, hipMalloc(&h->klst, need));
+            h->klst_bytes = need;
+        }
+        if (h->prec == NNLM_PREC_F64) launch_kl_stream<double>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
+        else launch_kl_stream<float>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     if (which == 0 && !speculative) swap_w(h);
@@ -1192,6 +1411,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     h->sg_request = false;
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
     if (h->any_missing && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
+    if (generic_rank(h) && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d is not sharded across GPUs in this build", NNLM_KQ_MAX);
     if (partial_only) phase = PH_A;
     if (phase == PH_B || phase == PH_C) {
         const HalfPlan pp = plan_half(h, which, h->rank, h->nranks);
@@ -1210,7 +1430,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // constants of the sweep (no sweep_consts launch), and nothing waits on another stream.
     static int one_stream_env = getenv("NNLM_ONE_STREAM") ? atoi(getenv("NNLM_ONE_STREAM")) : 1;
     h->consts_ready = false;
-    if (one_stream_env && h->x16 && !h->sharded && !h->any_missing && method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
+    if (one_stream_env && h->x16 && !h->sharded && !h->any_missing && method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts &&
+        !generic_rank(h)) {
         // The fast sweep kernel (k_sweep_wgf.h) leaves max|x| and the Gram partial sums of the factor it solved -- the fixed
         // factor of the NEXT half-step -- behind, computed from its LDS image (+1 us per sweep): the three kernels in front of
         // the cross product are then factor16 (5 us), gram_fold (sum of the workgroups' slabs) and sweep_consts, none of
@@ -1282,7 +1503,10 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     if (h->x16) prepare_factor16(h, which);
     {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
-        if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
+        if (generic_rank(h)) {
+            int rcx = launch_xprod_generic(h, which, p);
+            if (rcx != NNLM_OK) return rcx;
+        } else if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
         else if (h->x16) launch_xprod16(h, which, p);
         else launch_xprod_nkq<float>(h, which, p);
     }
@@ -1291,7 +1515,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     int gslabs = 0;
     {
         ProfScope ps(h, P_GRAM, h->stream_g);
-        const int CE = (which == 1) ? XPROD_ROWB / (int)esize(h) : (h->x16 ? 64 : XPROD_NT_ROWS);
+        const int CE = stage_elems(h, which);
         int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
         const int lim = (which == 1) ? h->n : h->m;
         if (c1 > lim) c1 = lim;
@@ -1427,9 +1651,14 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                 if (rcg != NNLM_OK) return rcg;
             }
             a.Graw = h->Gcols;
-            launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
+            if (generic_rank(h)) {
+                int rcs = launch_sweep_generic(h, method, a, (size_t)h->KP * h->KP);
+                if (rcs != NNLM_OK) return rcs;
+            } else
+                launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
         } else if (a.ncols > a.col0) {
-            launch_sweep(h, method, a);
+            int rcs = launch_sweep(h, method, a);
+            if (rcs != NNLM_OK) return rcs;
             if (sg) { // the next half-step finds max and Gram partial sums of this factor
                 h->sg_nslabs = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
                 h->sg_par ^= 1;
@@ -1592,7 +1821,8 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
         size_t nb;
         // multi-GPU: each rank reduces its share of the j-tiles; the two sums are all-reduced below
-        const int tile = (h->prec == NNLM_PREC_F64) ? ERR_TILE : ERRF_TILE;
+        const bool err_generic = generic_rank(h) && h->prec == NNLM_PREC_F32; // rank > 64: the LDS-free kernel with fp32 A
+        const int tile = (h->prec == NNLM_PREC_F64 || err_generic) ? ERR_TILE : ERRF_TILE;
         const int tj = h->mpad / tile, per = (tj + h->nranks - 1) / h->nranks;
         const int jt0 = h->sharded ? (h->rank * per < tj ? h->rank * per : tj) : 0;
         const int jcnt = h->sharded ? ((jt0 + per < tj ? jt0 + per : tj) - jt0) : tj;
@@ -1602,6 +1832,10 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
             dim3 grid(h->npad / ERR_TILE, jcnt);
             nb = (size_t)grid.x * grid.y;
             errors_kernel<double><<<grid, 256, 0, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials, jt0);
+        } else if (err_generic) {
+            dim3 grid(h->npad / ERR_TILE, jcnt);
+            nb = (size_t)grid.x * grid.y;
+            errors_kernel<float><<<grid, 256, 0, st>>>((const float *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials, jt0);
         } else {
             dim3 grid(h->npad / ERRF_TILE, jcnt);
             nb = (size_t)grid.x * grid.y;
@@ -1762,7 +1996,7 @@ extern "C" int nnlm_shard_range(int n, int m, int precision, int which, int rank
     t.npad = round_up_i(n, NNLM_PAD_N);
     t.mpad = round_up_i(m, NNLM_PAD_M);
     const HalfPlan p = plan_half(&t, which, rank, nranks);
-    const int CE = (which == 1) ? XPROD_ROWB / (int)esize(&t) : (t.x16 ? 64 : XPROD_NT_ROWS);
+    const int CE = stage_elems(&t, which);
     const int lim = (which == 1) ? n : m;
     int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
     if (c1 > lim) c1 = lim;
@@ -1918,7 +2152,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // factor while W_i is still current, so it evaluates the error sums of (W_i, H_i) on the way
                 // (xprod16_err_kernel) and no separate pass over A is needed (NNLM_ERR_FUSED=0: separate kernel).
                 static int fused_ok = getenv("NNLM_ERR_FUSED") ? atoi(getenv("NNLM_ERR_FUSED")) : 1;
-                h->fuse_err = fused_ok && h->x16 && !h->any_missing;
+                h->fuse_err = fused_ok && h->x16 && !h->any_missing && !generic_rank(h);
                 h->fused_nb = 0;
                 rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true);
                 h->fuse_err = false;

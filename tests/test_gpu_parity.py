@@ -496,3 +496,102 @@ def test_fast_sweep_with_masks_and_early_finishers(shape, inner, itol):
     assert abs(sweeps - it_ref) <= max(2, it_ref // 200)
     # fully masked columns are untouched, bit for bit
     assert np.array_equal(Hn[:, ::11][:, 1:], H0[:, ::11][:, 1:])
+
+
+# ---- no rank limit, no contraction-length limit (k_generic.h, kl_stream_kernel) ------------------------------------------
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+@pytest.mark.parametrize("method", [1, 2, 3, 4])
+@pytest.mark.parametrize("k", [65, 80, 128])
+def test_rank_above_64_half_steps_match_oracle(pname, prec, tol, method, k):
+    """The reference has no rank limit (src/update_with_missing.cpp:17-24): K = 65, 80, 128 through both half-steps, with a
+    coordinate mask crossing the 64-bit word boundary and L1/L2/angle regularisation."""
+    n, m = 300, 170
+    rng = np.random.default_rng(k + method)
+    A = rng.random((n, m))
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    Hm = rng.random((k, m)) < 0.1
+    Hm[:, 3] = True  # a fully masked column
+    H0[Hm] = 0.0
+    reg = [0.02, 0.01, 0.03]
+    inner = 4 if method < 3 else 2
+    if method >= 3 and pname == "f32":
+        tol = 1e-4
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(k, W0, H0, None, Hm)
+        h.half_step(0, reg, inner, 1e-9, method)
+        W1, _ = h.get_factors()
+        s1 = h.take_sweeps()
+        Wt_ref, it1 = ref.update(W0.T.copy(), H0, A.T.copy(), None, reg, inner, 1e-9, method)
+        assert relF(W1, Wt_ref.T) < tol
+        h.half_step(1, reg, inner, 1e-9, method)
+        _, H1 = h.get_factors()
+        s2 = h.take_sweeps()
+        H_ref, it2 = ref.update(H0, Wt_ref, A, Hm, reg, inner, 1e-9, method)
+        assert relF(H1, H_ref) < 10 * tol
+        assert np.array_equal(H1[Hm], H0[Hm])
+        mse, kl, _ = h.errors()
+        assert abs(mse - np.mean((A - W1 @ H1) ** 2)) < 1e-5 * mse
+        if pname == "f64":
+            assert (s1, s2) == (it1, it2)
+
+
+@pytest.mark.parametrize("pname,tol", [("f64", 1e-9), ("f32", 1e-4)])
+@pytest.mark.parametrize("method", [1, 3])
+def test_rank_above_64_driver_with_missing_values(monkeypatch, pname, tol, method):
+    """nnmf(k = 70) on a matrix with missing entries (update_with_missing with per-column 70 x 70 Grams) through the one-shot
+    entry, traces and factors against the oracle."""
+    monkeypatch.setenv("NNLM_PRECISION", pname)
+    rng = np.random.default_rng(70 + method)
+    n, m, k = 220, 140, 70
+    A = rng.random((n, m))
+    A.ravel()[rng.choice(A.size, A.size // 10, replace=False)] = np.nan
+    W0, H0 = 0.1 * rng.random((n, k)), 0.1 * rng.random((k, m))
+    args = (A, k, W0, H0, None, None, [0.01, 0, 0.01], [0.01, 0, 0.01], 4, -1.0, 1, 0, False, 6 if method == 1 else 1, 1e-9, method, 2)
+    r, o = nnlm_amd.c_nnmf(*args), ref.c_nnmf(*args)
+    assert relF(r["W"], o["W"]) < tol and relF(r["H"], o["H"]) < tol
+    assert r["n_iteration"] == o["n_iteration"] and len(r["mse_error"]) == len(o["mse_error"])
+    assert np.allclose(r["mse_error"], o["mse_error"], rtol=max(10 * tol, 1e-8)) and np.allclose(r["mkl_error"], o["mkl_error"], rtol=max(10 * tol, 1e-8))
+    if pname == "f64":
+        assert np.array_equal(r["average_epoch"], o["average_epoch"])
+
+
+def test_nnlm_with_more_than_64_predictors(monkeypatch):
+    """nnlm(x, y) is update() with rank = ncol(x) (src/nnlm.cpp:44-47): 90 predictors, long solve, default (fp64) precision."""
+    monkeypatch.delenv("NNLM_PRECISION", raising=False)
+    rng = np.random.default_rng(90)
+    x = rng.random((400, 90))
+    b = rng.random((90, 3)) * (rng.random((90, 3)) > 0.4)
+    y = x @ b + 0.01 * rng.standard_normal((400, 3))
+    b0 = rng.random((90, 3))
+    r = nnlm_amd.c_nnlm(x, y, [0, 0, 0], None, b0, 2000, 1e-10, 1, 1)
+    o = ref.c_nnlm(x, y, [0, 0, 0], None, b0, 2000, 1e-10, 1, 1)
+    assert relF(r["coefficient"], o["coefficient"]) < 1e-9 and r["n_iteration"] == o["n_iteration"]
+    assert np.all(r["coefficient"] >= 0)
+
+
+@pytest.mark.parametrize("pname,prec,tol", [("f64", _lib.PREC_F64, 1e-10), ("f32", _lib.PREC_F32, 1e-4)])
+@pytest.mark.parametrize("method", [3, 4])
+def test_kl_contraction_longer_than_32768(pname, prec, tol, method):
+    """nnmf(loss = 'mkl') on a 40000 x 9 matrix: the H half-step contracts over 40000 rows (the reference streams any
+    length, src/base_algorithms.cpp:71-151), the W half-step solves 40000 columns."""
+    rng = np.random.default_rng(method)
+    n, m, k = 40000, 9, 3
+    A = rng.random((n, m))
+    A[rng.random((n, m)) < 0.02] = np.nan
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    reg = [0.01, 0.0, 0.02]
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(k, W0, H0)
+        h.half_step(1, reg, 3, 1e-9, method)
+        _, H1 = h.get_factors()
+        sw = h.take_sweeps()
+        H_ref, it = ref.update(H0, W0.T.copy(), A, None, reg, 3, 1e-9, method)
+        assert relF(H1, H_ref) < tol
+        if pname == "f64":
+            assert sw == it
+        h.half_step(0, reg, 2, 1e-9, method)
+        W1, _ = h.get_factors()
+        Wt_ref, _ = ref.update(W0.T.copy(), H_ref, A.T.copy(), None, reg, 2, 1e-9, method)
+        assert relF(W1, Wt_ref.T) < 10 * tol
