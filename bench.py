@@ -6,13 +6,22 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one outer iteration of nnmf(): W half-step + H half-step (src/nnmf.cpp:114-133) plus, every `trace`
-steps, the error block (src/nnmf.cpp:135-160).  Workload = BASELINE.json configs[1]: nnmf(A, k=50), MSE loss,
+steps, the error block (src/nnmf.cpp:135-160).  Default workload = BASELINE.json configs[1]: nnmf(A, k=50), MSE loss,
 sequential coordinate descent, dense A 20000 x 10000 = U(0,1) synthetic, explicit 0.01*U(0,1) init, R defaults
 inner.max.iter=50, inner.rel.tol=1e-9, trace=2, rel.tol=-1 (fixed work).  A, W, H are resident in HBM when the timed
 region starts.  N > 1: A replicated, each rank contracts its slab, one RCCL all-reduce per half-step (strong scaling).
+`--config 3` / `--config 5` time BASELINE.json configs[2] (KL + Lee) / configs[4] (10 % NA + L1/L2) the same way (second
+bench lines for profiles/; the driver's line is the default config 2).  `--protocol core` = SURVEY section 8d's P-core (no
+error block inside the timed iterations).
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (the A-streaming cross-product kernel,
-HIP-event timed inside this process) and `cpu_baseline` (oracle/nnlm_ref.c, OpenMP, on this box's host cores).
+Prints ONE JSON line on rank 0 (see the task contract) with
+  roofline            the kernel class with the largest share of the step (HIP-event timed inside this process),
+  roofline_secondary  the A-streaming cross product (HBM bound) when it is not the dominant class,
+  step                whole-step fractions: SURVEY section 8d's bytes per iteration / time against the HBM peak, it/s against
+                      its ceiling,
+  cpu_baseline        oracle/nnlm_ref.c (OpenMP) on this box's host cores over the SAME iteration window (it starts from the
+                      factors the GPU had after its warm-up), plus a single-thread figure (n.threads = 1 is R's default),
+  mse_check           GPU and CPU mse after the same number of iterations from the same state.
 """
 import argparse
 import json
@@ -25,65 +34,95 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TF = 78.6        # fp64 vector = matrix peak
+# KL solvers: 3 plain + 1 transcendental fp32 instruction per element and coordinate = 14.9 cycles per 64 elements per SIMD
+# measured in isolation (scripts/exp/valu_exp.hip, "KL body packed"): 1024 SIMDs x 64 / 14.9 x 2.4 GHz
+KL_PEAK_GELEM = 1024 * 64 / 14.9 * 2.4
 N_, M_, K_ = 20000, 10000, 50
-INNER, INNER_TOL, METHOD = 50, float(os.environ.get("NNLM_BENCH_INNER_TOL", "1e-9")), 1  # (env: experiments only)
+INNER_TOL = float(os.environ.get("NNLM_BENCH_INNER_TOL", "1e-9"))  # (env: experiments only)
 SEED = 20250928
 
+CONFIGS = {
+    2: dict(name="nnmf(A, k={k}) MSE+SCD on {n}x{m} dense A (BASELINE.json configs[1])", method=1, inner=50, trace=2, reg=[0.0, 0.0, 0.0], na=False),
+    3: dict(name="nnmf(A, k={k}) KL loss + Lee multiplicative update on {n}x{m} dense A (BASELINE.json configs[2])", method=4, inner=1, trace=100,
+            reg=[0.0, 0.0, 0.0], na=False),
+    5: dict(name="nnmf(A, k={k}) MSE+SCD with 10% NA + L1/L2 reg on {n}x{m} A (BASELINE.json configs[4])", method=1, inner=50, trace=2,
+            reg=[0.01, 0.0, 0.01], na=True),
+}
 
-def make_inputs(n, m, k):
+
+def make_inputs(n, m, k, na):
     rng = np.random.default_rng(SEED)
     A = rng.random((n, m))
     W0 = 0.01 * rng.random((n, k))
     H0 = 0.01 * rng.random((k, m))
+    if na:
+        A = A.copy()
+        A.ravel()[np.random.default_rng(7).choice(n * m, n * m // 10, replace=False)] = np.nan
     return A, W0, H0
 
 
-def run_steps(h, steps, trace, first_index=0):
+def run_steps(h, cfg, steps, trace):
     """`steps` outer iterations of the reference loop (src/nnmf.cpp:109-161) on the resident problem: W half-step,
     H half-step, error block every `trace` iterations (+ the closing one), rel.tol = -1 so that no iteration is skipped.
-    This is nnlm_run(), the same code path nnlm_c_nnmf() takes after its upload.  Returns the last mse."""
-    z = [0.0, 0.0, 0.0]
-    r = h.run(z, z, steps, -1.0, 0, False, INNER, INNER_TOL, METHOD, trace if trace > 0 else 999999)
+    This is nnlm_run(), the same code path nnlm_c_nnmf() takes after its upload.  Returns the traces."""
+    r = h.run(cfg["reg"], cfg["reg"], steps, -1.0, 0, False, cfg["inner"], INNER_TOL, cfg["method"], trace if trace > 0 else 999999)
     assert r["n_iteration"] == steps
-    return float(r["mse_error"][-1])
+    return r
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm_summary.txt,
     separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command; KiB per dispatch).  gfx950 correction
     (MI355X_MICROARCH.md, HBM section): a wide streaming read is tallied at half its bytes, so reads = 2 x FETCH_SIZE.
-    bench.py cannot attach rocprofv3 to itself: (None, None) when no summary is committed."""
+    bench.py cannot attach rocprofv3 to itself: (None, None) when no summary holding the kernel is committed."""
     import glob, re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_summary.txt")),
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.txt")),
                    key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v10 after r01_v9
-    if not files:
-        return None, None
-    fetch = write = None
-    for line in open(files[-1]):
-        if kernel in line:
-            mt = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.eE+-]+)", line)
-            if mt and mt.group(1) == "FETCH_SIZE":
-                fetch = float(mt.group(2))
-            elif mt:
-                write = float(mt.group(2))
-    if fetch is None:
-        return None, None
-    return (2.0 * fetch + (write or 0.0)) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (2 x FETCH_SIZE + WRITE_SIZE, KiB per dispatch)"
+    for path in reversed(files):
+        fetch = write = None
+        for line in open(path):
+            if kernel in line:
+                mt = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.eE+-]+)", line)
+                if mt and mt.group(1) == "FETCH_SIZE":
+                    fetch = float(mt.group(2))
+                elif mt:
+                    write = float(mt.group(2))
+        if fetch is not None:
+            return (2.0 * fetch + (write or 0.0)) * 1024.0, "profiles/" + os.path.basename(path) + " (2 x FETCH_SIZE + WRITE_SIZE, KiB per dispatch)"
+    return None, None
 
 
-def cpu_baseline(A, W0, H0, k, iters, trace):
+def cpu_baseline(A, Ww, Hw, k, cfg, iters, trace):
+    """oracle/nnlm_ref.c from the warmed factors (the window the GPU's timed region covers), all host threads; plus the
+    single-thread cost of one iteration extrapolated from 1/32 of each half-step's columns (a full single-thread iteration
+    takes about a minute)."""
     from oracle import ref
     ref.lib()
     cores = os.cpu_count() or 1
+    n, m = A.shape
+    z = cfg["reg"]
     t0 = time.perf_counter()
-    r = ref.c_nnmf(A, k, W0, H0, None, None, [0, 0, 0], [0, 0, 0], iters, -1.0, 0, 0, False, INNER, INNER_TOL, METHOD, trace)
+    r = ref.c_nnmf(A, k, Ww, Hw, None, None, z, z, iters, -1.0, 0, 0, False, cfg["inner"], INNER_TOL, cfg["method"], trace)
     dt = time.perf_counter() - t0
-    return dict(value=iters / dt, unit="iterations/s", cores=cores, kind="port",
-                sample=f"{iters} outer iterations of the same 20000x10000 k=50 MSE+SCD problem (same A, W0, H0, trace={trace}) "
-                       f"with oracle/nnlm_ref.c (C/OpenMP restatement with the reference's cost structure, hand-written loops "
-                       f"instead of BLAS), n.threads = all {cores} host threads",
-                seconds=dt, final_mse=float(r["mse_error"][-1]))
+    out = dict(value=iters / dt, unit="iterations/s", cores=cores, kind="port",
+               sample=f"{iters} outer iterations of the same problem (same A; W, H as the GPU had them after its warm-up; trace={trace}) "
+                      f"with oracle/nnlm_ref.c (C/OpenMP restatement with the reference's cost structure, hand-written loops "
+                      f"instead of BLAS), n.threads = all {cores} host threads",
+               seconds=dt, final_mse=float(r["mse_error"][-1]), average_epoch=float(np.sum(r["average_epoch"]) / max(iters, 1)))
+    frac = 32
+    mc, nc = max(m // frac, 1), max(n // frac, 1)
+    t0 = time.perf_counter()
+    ref.update(Hw[:, :mc].copy(), Ww.T.copy(), np.ascontiguousarray(A[:, :mc]), None, z, cfg["inner"], INNER_TOL, cfg["method"], n_threads=1)
+    th = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref.update(Ww[:nc].T.copy(), Hw, np.ascontiguousarray(A[:nc].T), None, z, cfg["inner"], INNER_TOL, cfg["method"], n_threads=1)
+    tw = time.perf_counter() - t0
+    out["threads1"] = dict(value=1.0 / (m / mc * th + n / nc * tw), unit="iterations/s", cores=1,
+                           sample=f"one H half-step over the first {mc} of {m} columns ({th:.2f} s) and one W half-step over the first {nc} of {n} rows "
+                                  f"({tw:.2f} s) on ONE thread (R's default n.threads = 1), scaled to all columns; A.t() and the error block not included")
+    return out, r
 
 
 def main():
@@ -91,13 +130,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--trace", type=int, default=2, help="error block every TRACE steps (R default 2 for MSE); 0 = never")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="2 (default, the headline), 3 (KL+Lee), 5 (NA + reg)")
+    ap.add_argument("--trace", type=int, default=None, help="error block every TRACE steps (R default: 2 for MSE, 100 for MKL); 0 = never")
+    ap.add_argument("--protocol", default="default", choices=["default", "core"], help="core: no error block inside the timed iterations (SURVEY 8d)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-iters", type=int, default=2, help="outer iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions (the first one is `value`; all are listed)")
     ap.add_argument("--size", default=None, help="n,m,k override for quick experiments (reported in config)")
     args = ap.parse_args()
 
+    cfg = dict(CONFIGS[args.config])
     n, m, k = (int(v) for v in args.size.split(",")) if args.size else (N_, M_, K_)
+    trace = cfg["trace"] if args.trace is None else args.trace
+    if args.protocol == "core":
+        trace = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,17 +156,21 @@ def main():
     import nnlm_amd
     from nnlm_amd import _lib
 
+    # NNLM_BENCH_FORCE_COMM=1: build the communicator and take the sharded code path with ONE rank (tests the N > 1 plumbing --
+    # id broadcast, LOCAL_RANK -> device, barriers, max-over-ranks -- on a one-GPU box)
+    force_comm = os.environ.get("NNLM_BENCH_FORCE_COMM", "") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or force_comm:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    A, W0, H0 = make_inputs(n, m, k)
+    A, W0, H0 = make_inputs(n, m, k, cfg["na"])
     prec = _lib.PREC_F64 if args.precision == "f64" else _lib.PREC_F32
     h = nnlm_amd.Handle(local_rank, prec)
-    if world > 1:
+    if dist is not None:
         ids = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         h.comm_init(ids[0], rank, world)
@@ -135,25 +185,32 @@ def main():
             dist.barrier()
         h.sync()
 
-    run_steps(h, args.warmup, args.trace, 0)
-    barrier()
-    t0 = time.perf_counter()
-    mse = run_steps(h, args.steps, args.trace, args.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
+    def max_over_ranks(x):
+        if dist is None:
+            return x
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    final_mse = h.errors()[0] if mse is None else mse
+        return float(t[0])
+
+    run_steps(h, cfg, args.warmup, trace)
+    Ww, Hw = h.get_factors()  # the state both the timed region and the CPU sample start from
+    times, mses = [], []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        r = run_steps(h, cfg, args.steps, trace)
+        barrier()
+        times.append(max_over_ranks(time.perf_counter() - t0))
+        mses.append(float(r["mse_error"][-1]))
+    elapsed, final_mse = times[0], mses[0]
 
     # replay the same K steps with per-kernel HIP events (on the library's own stream) for the roofline block
     h.profile_reset()
     h.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
-    run_steps(h, args.steps, args.trace, args.warmup + args.steps)
+    run_steps(h, cfg, args.steps, trace)
     barrier()
     prof_elapsed = time.perf_counter() - t0
     kern = {}
@@ -162,6 +219,12 @@ def main():
         kern[name] = dict(ms_per_launch=(ms / cnt if cnt else None), launches=cnt, total_ms=ms)
     h.profile_enable(False)
 
+    # GPU mse after `cpu_iters` iterations from the warmed state (what the CPU sample reproduces)
+    gpu_check = None
+    if args.cpu_iters > 0 and world == 1 and not force_comm:
+        h.set_factors(k, Ww, Hw)
+        gpu_check = run_steps(h, cfg, args.cpu_iters, trace)
+
     if rank != 0:
         h.close()
         if dist is not None:
@@ -169,42 +232,82 @@ def main():
         return
 
     s = 8 if args.precision == "f64" else 4
-    # algorithmic HBM bytes of ONE cross-product launch (DESIGN.md "Roofline accounting"): A once, the fixed factor
-    # once, the fp64 cross product once.  At N ranks each rank streams 1/N of A.
+    x16 = s == 4 and os.environ.get("NNLM_XPROD", "") != "f32"   # split-fp16 cross products: one kernel for both half-steps
+    inner, method = cfg["inner"], cfg["method"]
+    # ---- algorithmic work per launch of each kernel class (DESIGN.md section 4 / SURVEY section 8d) ---------------------
+    # cross products (HBM): A once, the fixed factor once, the fp64 cross product once; at N ranks each rank streams 1/N of A
     bytes_h = (n * m * s + k * n * s) / world + k * m * 8
     bytes_w = (n * m * s + k * m * s) / world + k * n * 8
-    dom = "xprod_w" if (kern["xprod_w"]["total_ms"] or 0) >= (kern["xprod_h"]["total_ms"] or 0) else "xprod_h"
-    dom_bytes = bytes_w if dom == "xprod_w" else bytes_h
-    dom_ms = kern[dom]["ms_per_launch"]
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
-    x16 = s == 4 and os.environ.get("NNLM_XPROD", "") != "f32"   # split-fp16 cross products: one kernel for both half-steps
-    if x16:  # the W half-step's launches mix xprod16_tn_kernel with the fused cross-product + error-block kernel: price the pure one
-        dom, dom_bytes = "xprod_h", bytes_h
-        dom_ms = kern[dom]["ms_per_launch"]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
-    kname = "xprod16_tn_kernel" if x16 else ("xprod_nt_kernel" if dom == "xprod_w" else "xprod_tn_kernel")
-    traffic, traffic_src = pmc_traffic(kname) if world == 1 else (None, None)
-    roofline = dict(bound="hbm", kernel=f"{dom} ({kname})", achieved=achieved,
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=(achieved / HBM_PEAK_GBS if achieved else None), traffic=traffic,
-                    traffic_source=traffic_src,
-                    bytes_per_launch=dom_bytes, ms_per_launch=dom_ms,
-                    mfma_tflops=(2.0 * n * m * k / world / (dom_ms * 1e-3) / 1e12 if dom_ms else None))
-    # the sweeps are a loop-carried recurrence (no HBM/MFMA roofline): reported as achieved fp64
-    # arithmetic of the recurrence itself, inner*cols*k*(2k+8) flops per launch, against the fp64 vector peak
-    sweep_info = {}
-    for kname, cols in (("sweep_h", m), ("sweep_w", n)):
-        ms_l = kern[kname]["ms_per_launch"]
-        if ms_l:
-            fl = INNER * (cols / world) * k * (2 * k + 8)
-            sweep_info[kname] = dict(flops_per_launch=fl, tflops=fl / (ms_l * 1e-3) / 1e12, frac_of_fp64_peak=fl / (ms_l * 1e-3) / 1e12 / 78.6,
-                                     note="latency bound: 2500 dependent coordinate steps per column")
+    classes = {}
+    if method < 3:
+        for nm, by in (("xprod_h", bytes_h), ("xprod_w", bytes_w)):
+            if kern[nm]["ms_per_launch"]:
+                # (trace iterations run the fused cross-product + error-block kernel in xprod_w: its launches are averaged in)
+                kname = "xprod16_tn_kernel" if x16 else ("xprod_nt_kernel" if nm == "xprod_w" else "xprod_tn_kernel")
+                classes[nm] = dict(bound="hbm", kernel=f"{nm} ({kname})", work=by, peak=HBM_PEAK_GBS, unit="GB/s", scale=1e9, pmc=kname)
+        for nm, cols in (("sweep_h", m), ("sweep_w", n)):
+            if kern[nm]["ms_per_launch"]:
+                # the sweeps are a loop-carried recurrence (SURVEY 8d grants them no HBM/MFMA roofline): priced as achieved fp64
+                # arithmetic of the recurrence, inner*cols*k*(2k+8) flops per launch, against the fp64 matrix/vector peak
+                fl = inner * (cols / world) * k * (2 * k + 8)
+                knm = "na_gram_mfma_kernel + colsolve" if cfg["na"] else "sweep_scd_wgf_kernel"
+                if cfg["na"]:
+                    fl += 2.0 * k * k * (n * m // 10)  # per-column Grams over the complement rows (2 k^2 per missing entry)
+                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=FP64_PEAK_TF, unit="TFLOP/s", scale=1e12, pmc=None,
+                                   note="latency bound: inner*k dependent coordinate steps per column; flops = inner*cols*k*(2k+8)"
+                                        + (" + 2k^2 per missing entry (per-column Grams)" if cfg["na"] else ""))
+    else:
+        for nm in ("sweep_h", "sweep_w"):
+            if kern[nm]["ms_per_launch"]:
+                el = float(n) * m * k * inner  # element-steps: every entry of A meets every coordinate once per sweep
+                classes[nm] = dict(bound="valu", kernel=f"{nm} (wh_store_kernel + kl_tile_kernel)", work=el, peak=KL_PEAK_GELEM, unit="Gelem/s", scale=1e9, pmc=None,
+                                   note="fp32 VALU: 3 plain + 1 v_rcp_f32 per element and coordinate; peak = 14.9 cycles per 64 elements per SIMD "
+                                        "(scripts/exp/valu_exp.hip)")
+    if kern["errors"]["ms_per_launch"] and "errors" not in classes:
+        classes["errors"] = dict(bound="hbm", kernel="errors (errors_f32_kernel / reduction of the fused sums)", work=n * m * s / world, peak=HBM_PEAK_GBS,
+                                 unit="GB/s", scale=1e9, pmc=None)
+
+    def block(nm):
+        c = classes[nm]
+        ms_l = kern[nm]["ms_per_launch"]
+        ach = c["work"] / (ms_l * 1e-3) / c["scale"]
+        traffic, src = (pmc_traffic(c["pmc"]) if (c["pmc"] and world == 1) else (None, None))
+        b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
+                 traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
+        if "note" in c:
+            b["note"] = c["note"]
+        return b
+
     total_k = sum(v["total_ms"] for v in kern.values()) or 1.0
     shares = {kname: round(v["total_ms"] / total_k, 4) for kname, v in kern.items()}
+    ranked = sorted((nm for nm in classes if nm != "errors"), key=lambda nm: -kern[nm]["total_ms"])
+    roofline = block(ranked[0]) if ranked else None
+    if roofline:
+        roofline["share_of_kernel_time"] = shares[ranked[0]]
+    secondary = None
+    xp = [nm for nm in ranked if classes[nm]["bound"] == "hbm"]
+    if xp and xp[0] != ranked[0]:
+        secondary = block(xp[0])
+        secondary["share_of_kernel_time"] = shares[xp[0]]
+    all_blocks = {nm: block(nm) for nm in classes}
 
-    cpu = None
-    if args.cpu_iters > 0 and world == 1:  # the CPU baseline is timed on rank 0 at N=1 only
-        cpu = cpu_baseline(A, W0, H0, k, args.cpu_iters, args.trace if args.trace > 0 else 999999)
+    # whole step against SURVEY 8d's per-iteration figures (config 2): bytes A twice + factors, +A once on trace iterations
+    ms_step = 1e3 * elapsed / args.steps
+    b_it = 2.0 * n * m * s + 4.0 * k * (n + m) * s + (n * m * s / trace if trace > 0 else 0.0)
+    f_it = 4.0 * n * m * k + 4.0 * k * k * (n + m)
+    ceil_ms = max(b_it / (HBM_PEAK_GBS * 1e9), f_it / 157.3e12) * 1e3 if s == 4 else max(b_it / (HBM_PEAK_GBS * 1e9), f_it / 78.6e12) * 1e3
+    step = dict(bytes_per_iteration=b_it, hbm_frac=b_it / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, ceiling_it_per_s=1e3 / ceil_ms,
+                frac_of_ceiling=(args.steps / elapsed) / (1e3 / ceil_ms),
+                note="SURVEY 8d: B_it = 2nm s + 4k(n+m)s (+ nm s per trace iteration); ceiling = max(B_it / 8 TB/s, F_it / MFMA peak)") if method < 3 and not cfg["na"] else None
 
+    cpu = mse_check = None
+    if args.cpu_iters > 0 and world == 1 and not force_comm:  # the CPU baseline is timed on rank 0 at N=1 only
+        cpu, rc = cpu_baseline(A, Ww, Hw, k, cfg, args.cpu_iters, trace if trace > 0 else 999999)
+        g, c_ = float(gpu_check["mse_error"][-1]), float(rc["mse_error"][-1])
+        mse_check = dict(iterations_from_warm_state=args.cpu_iters, gpu=g, cpu=c_, rel_diff=abs(g - c_) / c_,
+                         gpu_average_epoch=float(np.sum(gpu_check["average_epoch"]) / args.cpu_iters), cpu_average_epoch=cpu["average_epoch"])
+
+    ms_all = [1e3 * t / args.steps for t in times]
     out = {
         "metric": "nnmf iterations/sec + final MSE, dense A 20000x10000 k=50, 1/2/4/8 GPU",
         "value": args.steps / elapsed,
@@ -212,27 +315,33 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": ms_step,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
         "final_mse": final_mse,
-        "config": {"workload": f"nnmf(A, k={k}) MSE+SCD on {n}x{m} dense A (BASELINE.json configs[1])", "n": n, "m": m, "k": k,
-                   "inner_max_iter": INNER, "inner_rel_tol": INNER_TOL, "trace": args.trace, "rel_tol": -1,
+        "config": {"workload": cfg["name"].format(n=n, m=m, k=k), "n": n, "m": m, "k": k, "method": method,
+                   "inner_max_iter": inner, "inner_rel_tol": INNER_TOL, "trace": trace, "protocol": args.protocol, "rel_tol": -1,
+                   "reg": cfg["reg"],
                    "arith": (("A fp32 (4 B/element); cross products: operands as split fp16 pairs (hi + lo*2^-11, 22 bits) on "
                               "v_mfma_f32_16x16x32_f16 with fp32 accumulation folded into fp64 every 256 elements"
                               if os.environ.get("NNLM_XPROD", "") != "f32" else
-                              "A + cross-product GEMMs fp32 MFMA (fp64 flush every 256)") + "; Gram/mu/sweeps fp64" if s == 4
+                              "A + cross-product GEMMs fp32 MFMA (fp64 flush every 256)") + "; Gram/mu/sweeps fp64; KL solvers fp32 state" if s == 4
                              else "all fp64 (v_mfma_f64_16x16x4_f64)"),
                    "parallelism": (f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
-                                   if world > 1 else "1 GPU")},
+                                   if (world > 1 or force_comm) else "1 GPU")},
+        "repeats": {"ms_per_step": ms_all, "min": min(ms_all), "median": float(np.median(ms_all)), "max": max(ms_all),
+                    "final_mse": mses, "note": "consecutive timed regions of `steps` iterations each; `value` is the first"},
         "roofline": roofline,
+        "roofline_secondary": secondary,
+        "roofline_all": all_blocks,
+        "step": step,
         "cpu_baseline": cpu,
+        "mse_check": mse_check,
         "kernels": kern,
         "kernel_time_share": shares,
-        "sweeps": sweep_info,
         "profiled_ms_per_step": 1e3 * prof_elapsed / args.steps,
         "upload_and_prep_s": upload_s,
     }

@@ -153,8 +153,10 @@ int nnlm_profile_reset(nnlm_handle *h);
  * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated.  Per half-step each rank
  * contracts its slab of rows (H half-step) / columns (W half-step); ONE ncclAllReduce sums the
  * partial [Gram | cross-product] buffer; each rank then solves its own 1/N of the columns and ONE
- * ncclAllGather returns the updated factor to every rank.  Error block: each rank reduces its
- * share of A, two doubles are all-reduced.
+ * ncclAllGather returns the updated factor to every rank.  With missing values (per-column Grams)
+ * and for the KL methods the column is the unit: a rank does all the work of its columns over the
+ * whole contraction and only the all-gather remains.  Error block: each rank reduces its share of
+ * A, two doubles are all-reduced.
  * ---------------------------------------------------------------------------------------- */
 #define NNLM_COMM_ID_BYTES 128
 int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */
@@ -165,6 +167,9 @@ int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks);
 /* Contraction range [begin, end) owned by `rank` of `nranks`: rows i of A for the H half-step (which = 1), columns j
  * for the W half-step (which = 0).  Pure function of the sizes (no device needed). */
 int nnlm_shard_range(int n, int m, int precision, int which, int rank, int nranks, int *begin, int *end);
+/* Columns [col0, col1) of the factor being solved (m columns of H for which = 1, n rows of A = columns of W^T for which = 0) that
+ * `rank` solves, and the width cpr of the packed slab [k][cpr] every rank contributes to the all-gather.  Pure function. */
+int nnlm_shard_cols(int ncols, int rank, int nranks, int *cpr, int *col0, int *col1);
 /* Test hook: partial [Gram k x k | cross product k x cols] of this (virtual) rank's slab, column-major, before the
  * all-reduce and before the regularisation edits of src/update_with_missing.cpp:20-24. */
 int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out);

@@ -25,7 +25,7 @@ EXPORTS = [
     "nnlm_abi_version", "nnlm_set_matrix", "nnlm_matrix_info", "nnlm_set_factors", "nnlm_get_factors",
     "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
-    "nnlm_shard_range", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
+    "nnlm_shard_range", "nnlm_shard_cols", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
 ]
 
 
@@ -109,6 +109,8 @@ def load():
     lib.nnlm_comm_info.argtypes = [vp, ip, ip]
     lib.nnlm_shard_range.restype = C.c_int
     lib.nnlm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
+    lib.nnlm_shard_cols.restype = C.c_int
+    lib.nnlm_shard_cols.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip]
     lib.nnlm_debug_partial.restype = C.c_int
     lib.nnlm_debug_partial.argtypes = [vp, C.c_int, dp, dp]
     lib.nnlm_debug_phase.restype = C.c_int
@@ -354,6 +356,13 @@ def shard_range(n, m, precision, which, rank, nranks):
     b, e = C.c_int(0), C.c_int(0)
     _check(load().nnlm_shard_range(int(n), int(m), int(precision), int(which), int(rank), int(nranks), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def shard_cols(ncols, rank, nranks):
+    """(cpr, col0, col1): the columns `rank` solves and the packed slab width (pure host function of the C ABI)."""
+    cpr, c0, c1 = C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(load().nnlm_shard_cols(int(ncols), int(rank), int(nranks), C.byref(cpr), C.byref(c0), C.byref(c1)))
+    return cpr.value, c0.value, c1.value
 
 
 def debug_exchange(handles, which, stage):

@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void gram_partial_generic_kernel(const double 
 // threads in passes of 256 x 8; the listed rows pass through LDS 16 at a time.
 __global__ __launch_bounds__(256) void na_gram_generic_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
                                                               const double *__restrict__ Yrow, int KP, const double *__restrict__ Gfull,
-                                                              double *__restrict__ Gcols)
+                                                              double *__restrict__ Gcols, int col0 = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nag_smem[];
     double *rows = (double *)nag_smem; // [16][KP]
-    const int col = blockIdx.x, tid = threadIdx.x;
+    const int col = col0 + blockIdx.x, tid = threadIdx.x;
     const uint32_t mt = meta[col];
     const int len = (int)(mt & 0x7FFFFFFFu);
     const bool complement = (mt >> 31) != 0;

@@ -30,7 +30,7 @@ struct KlArgs {
     const uint32_t *bits; // missing mask of column c over the contraction index: bits[c*words + i/32] >> (i%32); NULL = none
     int words;
     int p;           // contraction length
-    int ncols, k;
+    int ncols, k;    // ncols: END of the column range solved (exclusive)
     double r0, r1, r2;
     const unsigned long long *mask;
     unsigned max_iter;
@@ -38,6 +38,9 @@ struct KlArgs {
     void *op;
     int op_mode, op_ld, op_f64;
     unsigned long long *sweeps;
+    // multi-GPU column shards: this launch solves columns col0 .. ncols-1 and writes entry (q, col) to Xout[q*ldo + col - ocol0]
+    // (a packed per-rank slab for the all-gather); single GPU: col0 = ocol0 = 0, ldo = ldx
+    int col0 = 0, ldo = 0, ocol0 = 0;
 };
 
 // block-wide sum of NV values, identical result in every thread; `red` is [2][NV][8] doubles, `par` alternates 0/1
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     __shared__ double xs[64];
     __shared__ double red[2 * 3 * 8];
     const int tid = threadIdx.x;
-    const int col = blockIdx.x;
+    const int col = a.col0 + blockIdx.x;
     const int k = a.k, p = a.p;
 
     unsigned long long mword = 0ull;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
     __syncthreads();
     if (tid < k) {
         const double xv = xs[tid];
-        a.Xout[(size_t)tid * a.ldx + col] = xv;
+        a.Xout[(size_t)tid * a.ldo + (col - a.ocol0)] = xv;
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)tid * a.op_ld + col] = xv;
             else ((float *)a.op)[(size_t)tid * a.op_ld + col] = (float)xv;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
 // v_rcp_f64 + one Newton step; the rel-change test 2|d|/(..) > tol without the division.
 struct KlTileArgs {
     const float *Adata; // column c at Adata + c * lda, contraction index contiguous
-    size_t lda;
+    size_t lda;         // (= ldyf, a multiple of 4)
     const float *Yinit; // same layout: starting state vectors y = Yt^T x of all columns (wh_store_kernel)
     const float *Yf;    // [k][ldyf] fp32 fixed factor, contraction index contiguous, zero beyond p
     int ldyf;
@@ -203,6 +206,7 @@ struct KlTileArgs {
     const double *X;
     double *Xout;
     int ldx;
+    int colbase, ldo, ocol0; // first column of this launch; entry (q, col) goes to Xout[q*ldo + col - ocol0] (KlArgs)
     const double *sumw;      // [k]: sum over the contraction index of row q of the fixed factor, or
     const double *sumw_cols; // [ncols][ldsw]: the same restricted to the non-missing entries of each column (NULL: dense)
     int ldsw;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     double *sws = xs + C * k;                            // [C][k]
     float *red = (float *)(sws + C * k);                 // [2][NV * C][8]
     unsigned long long *mks = (unsigned long long *)(red + 2 * 2 * C * 8); // [C][mw] mask words of the block's columns (a.mask only)
-    const int col0 = blockIdx.x * C;
+    const int col0 = a.colbase + blockIdx.x * C;
     const float tiny = (float)NNLM_TINY;
 
     // pieces e = 0 .. nlw-1 of a row (float4 slots e * 512 + 64 * wave + lane) belong to this wavefront: it loads them, reads
@@ -278,12 +282,21 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     int nlw = 0;
 #pragma unroll
     for (int e = 0; e < EPT4; e++) nlw += (e * KLT_THREADS + wave * 64 < P4) ? 1 : 0;
-    const int voff = lane * 16;
+    // Slots at or beyond L4 = ld / 4 (only in a row's last piece; the arrays end there) are never loaded: they are zeroed here
+    // once in both buffers, their state entries are b = 0, y = 1, so they add nothing and never change.
+    const int voff = lane * 16, L4 = (int)(a.lda >> 2);
+    for (int i = L4 + tid; i < P4; i += KLT_THREADS) {
+        *(f32x4 *)(kl_smem + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4 *)(kl_smem + (size_t)rowb + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto issue = [&](int q, int bufsel) {
         const unsigned char *row = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024; // wave-uniform
 #pragma unroll
         for (int e = 0; e < EPT4; e++)
-            if (e < nlw) glds16(row + (size_t)e * (KLT_THREADS * 16) + voff, kl_smem + (size_t)bufsel * rowb + (size_t)(e * KLT_THREADS + wave * 64) * 16);
+            if (e < nlw) {
+                if (e * KLT_THREADS + wave * 64 + lane < L4)
+                    glds16(row + (size_t)e * (KLT_THREADS * 16) + voff, kl_smem + (size_t)bufsel * rowb + (size_t)(e * KLT_THREADS + wave * 64) * 16);
+            }
     };
 
     bool live[C];
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
 #pragma unroll
         for (int e = 0; e < EPT4; e++) {
             const int idx4 = e * KLT_THREADS + tid;
-            const bool valid = e < nlw && col0 + c < a.ncols;
+            const bool valid = e < nlw && idx4 < L4 && col0 + c < a.ncols;
             b[c][e] = valid ? Ac[idx4] : f32x4{0.f, 0.f, 0.f, 0.f};
             y[c][e] = valid ? Yc[idx4] + tiny : f32x4{1.f, 1.f, 1.f, 1.f};
             // (a register use right here: otherwise the wait for this load lands at its first use inside the step loop, where
@@ -386,7 +399,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                         r[1] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][1]));
                         r[2] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][2]));
                         r[3] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][3]));
-                        if (METHOD == 4) {
+                        if constexpr (METHOD == 4) {
                             acc[c][0] = __builtin_elementwise_fma(w, b[c][e] * r, acc[c][0]); // Wt.row(k) * (Aj / (wh + eps)), :141
                         } else {
                             const f32x4 u = w * r;                                             // mu, :97
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         const int c = e / k, q = e - c * k, col = col0 + c;
         if (col < a.ncols) {
             const double xv = xs[e];
-            a.Xout[(size_t)q * a.ldx + col] = xv;
+            a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
             if (a.op_mode == 1) ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
             else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(256) void kl_stream_kernel(const KlArgs a, int mw, 
     double *xs = (double *)kls_smem; // [k]
     double *red = xs + a.k;          // [2][3][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = blockIdx.x, k = a.k, p = a.p;
+    const int col = a.col0 + blockIdx.x, k = a.k, p = a.p;
     T *ys = St + (size_t)col * 2 * ldst, *bs = ys + ldst;
     const uint32_t *bits = a.bits ? a.bits + (size_t)col * a.words : nullptr;
 
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(256) void kl_stream_kernel(const KlArgs a, int mw, 
     __syncthreads();
     for (int q = tid; q < k; q += 256) {
         const double xv = xs[q];
-        a.Xout[(size_t)q * a.ldx + col] = xv;
+        a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
             else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;

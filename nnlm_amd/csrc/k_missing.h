@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void factor_rows_kernel(const double *__restri
 template <int NKQ>
 __global__ __launch_bounds__(256) void na_gram_kernel(const uint32_t *__restrict__ bits_all, int words, int p,
                                                       const double *__restrict__ Yrow, const double *__restrict__ Gfull,
-                                                      double *__restrict__ Gcols)
+                                                      double *__restrict__ Gcols, int col0 = 0)
 {
     constexpr int KP = 16 * NKQ;
     constexpr int NB = KP / 4; // 4x4 register blocks per side
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void na_gram_kernel(const uint32_t *__restrict
     __shared__ int sel[256];
     __shared__ int nsel_s, cnt_s;
     __shared__ int wcnt[4];
-    const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = col0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t *bits = bits_all + (size_t)col * words;
 
     // number of missing rows in this column
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
 {
     constexpr int NCH = 2 * NKQ; // chunks of 8 coordinates
     const int lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col = a.col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= a.ncols) return; // whole wave
     const int k = a.k;
     const bool lv = lane < k;
@@ -311,12 +311,12 @@ __global__ __launch_bounds__(256) void na_fill_kernel(const uint32_t *__restrict
 template <int NKQ>
 __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
                                                            const double *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
-                                                           int ncols)
+                                                           int ncols, int col0 = 0)
 {
     constexpr int KP = 16 * NKQ;
     constexpr int NP = NKQ * (NKQ + 1) / 2;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col = col0 + blockIdx.x * 4 + (threadIdx.x >> 6); // columns col0 .. ncols-1
     if (col >= ncols) return; // whole wave
     const uint32_t mt = meta[col];
     const int len = (int)(mt & 0x7FFFFFFFu);
@@ -359,4 +359,115 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
                 out[i * KP + j] = v;
                 if (a != b) out[j * KP + i] = v;
             }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// colsolve_fast_kernel -- SCD-LS with a Gram of its own per column (or one shared Gram), fp32-operand mode (k <= 64).
+//
+// colsolve_ls_kernel above spends ~15 fp64 instructions per coordinate (four v_readlane pairs, reciprocal + Markstein
+// quotient, compare, select): 2.9 ms per half-step at config 5 against 0.19-0.24 ms for the dense sweep.  This kernel runs
+// the same recurrence in the arithmetic of k_sweep_wgf.h (rows of G divided by their diagonal, nu = mu / G[q][q],
+// d = max(-x, -nu): ONE instruction) with one wavefront per column, lane = coordinate, and six instructions per step:
+//     v_max_f64   dd   = max(-x, -nu)              every lane on its own coordinate; lane q's value is the step's delta
+//     v_readlane  d    = dd[q]            (x2)      -> SGPR pair
+//     v_fma_f64   nu  += d * Gs[q]                  Gs[q] = G[lane][q] / G[lane][lane] lives in a register (q is unrolled)
+//     v_writelane xd[q] = d               (x2)      deltas of the sweep, added to x once per sweep
+// A coordinate's x only matters at its own step, so x is brought up to date once per sweep (x += xd) and the rel-change
+// test of src/base_algorithms.cpp:29-32 runs once per sweep on all lanes: 2|xd| > tol (x_new + x_old + eps).
+// Results differ from colsolve_ls_kernel by rounding only (the deviations listed for k_sweep_wgf.h in DESIGN.md section 2).
+// Also the dense sweep for SMALL column counts (multi-GPU column shards): its duration is 2500 steps x ~40 cycles however
+// few columns there are, a quarter of the workgroup-specialised kernel's.
+template <int NKQ, bool HAS_MASK>
+__global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, size_t g_stride)
+{
+    constexpr int KP = 16 * NKQ;
+    const int lane = threadIdx.x & 63;
+    const int col = a.col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= a.ncols) return; // whole wavefront
+    const int k = a.k;
+    const bool lv = lane < k;
+    const int lq = lv ? lane : 0;
+    const double *G = a.Graw + (size_t)col * g_stride;
+    unsigned long long mword = 0ull;
+    if (HAS_MASK) mword = a.mask[col];
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const bool skip = HAS_MASK && ((mword & kmask) == kmask); // arma::all(mask.col(j)), src/update_with_missing.cpp:75-76
+
+    double gd = 1.0; // edited G[lane][lane] (src/update_with_missing.cpp:98-103)
+    if (lv) {
+        gd = G[(size_t)lq * a.KPg + lq];
+        if (a.r0 != a.r1) gd += a.r0 - a.r1;
+        if (a.r1 != 0) gd += a.r1;
+        gd += NNLM_TINY;
+    }
+    const double rgd = 1.0 / gd;
+    double gs[KP]; // row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
+#pragma unroll
+    for (int q = 0; q < KP; q++) {
+        double v = 0.0;
+        if (q < k && lv) {
+            v = G[(size_t)q * a.KPg + lane];
+            if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
+            if (a.r1 != 0) v += a.r1;
+            if (q == lane) v += NNLM_TINY;
+            v *= rgd;
+        }
+        gs[q] = v;
+    }
+    double x = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
+    double cv = 0.0;
+    if (lv)
+        for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)lq * a.ldc + col];
+    // nu = (G x - c + L1) / G[lane][lane]
+    double nu = lv ? (((a.r2 != 0) ? a.r2 - cv : -cv) * rgd) : 0.0;
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+        if (q < k) nu = __builtin_fma(readlane_f64(x, q), gs[q], nu);
+
+    unsigned t = 0;
+    if (!skip) {
+        bool more = true; // rel = 1 + rel_tol > rel_tol
+        for (; t < a.max_iter && more; t++) {
+            double xd = 0.0;
+            int kk = k;
+            asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
+            auto step = [&](const int q) {
+                double dd;
+                asm("v_max_f64 %0, -%1, -%2" : "=v"(dd) : "v"(x), "v"(nu)); // = max(0, x - nu) - x without the canonicalisation of fmax()
+                int2 dp = __builtin_bit_cast(int2, dd);
+                const int dlo = __builtin_amdgcn_readlane(dp.x, q), dhi = __builtin_amdgcn_readlane(dp.y, q);
+                nu = __builtin_fma(__builtin_bit_cast(double, int2{dlo, dhi}), gs[q], nu);
+                int2 xp = __builtin_bit_cast(int2, xd);
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xp.x) : "s"(dlo), "n"(q));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xp.y) : "s"(dhi), "n"(q));
+                xd = __builtin_bit_cast(double, xp);
+            };
+#pragma unroll
+            for (int c = 0; c < NKQ; c++) {
+                if (!HAS_MASK && 16 * c + 16 <= kk) { // a whole block of 16 coordinates: no per-step test
+#pragma unroll
+                    for (int e = 0; e < 16; e++) step(16 * c + e);
+                } else if (16 * c < kk) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
+                }
+            }
+            const double xn = x + xd;
+            const bool big = 2 * fabs(xd) > a.rel_tol * (xn + x + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
+            x = xn;
+            more = __ballot(big && lv) != 0ull || 0.0 > a.rel_tol;
+        }
+    }
+    if (lv) {
+        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = x;
+        if (a.op_mode == 1) {
+            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
+            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
+        } else if (a.op_mode == 2) {
+            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
+            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
+        }
+    }
+    if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }

@@ -538,6 +538,7 @@ static int split_plan(int tiles_x, int stages, int *S, int *sps)
 
 struct HalfPlan {
     int stage_begin, stage_end, S, sps, tiles_x;
+    int col_off = 0; // first column of the factor being solved that this launch covers (column shards of the multi-GPU NA path)
 };
 
 // which = 1: H half-step (TN, contraction over i); which = 0: W half-step (NT, contraction over j)
@@ -715,14 +716,15 @@ static void launch_xprod(nnlm_handle *h, int which, const HalfPlan &p)
         dim3 grid(p.tiles_x, p.S);
         const int lds = xprod_tn_lds_bytes(KP);
         hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Wop, h->npad, h->Cx, h->mpad,
-                                                                              (size_t)KP * h->mpad, p.stage_begin, p.stage_end, p.sps);
+        xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A + (size_t)p.col_off * h->npad, h->npad, (const T *)h->Wop,
+                                                                              h->npad, h->Cx + p.col_off, h->mpad, (size_t)KP * h->mpad, p.stage_begin,
+                                                                              p.stage_end, p.sps);
     } else {
         dim3 grid(p.tiles_x, p.S);
         const int lds = xprod_nt_lds_bytes<T>(KP);
         hipFuncSetAttribute((const void *)xprod_nt_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        xprod_nt_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A, h->npad, (const T *)h->Hop, h->Cx, h->npad,
-                                                                              (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
+        xprod_nt_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A + p.col_off, h->npad, (const T *)h->Hop, h->Cx + p.col_off,
+                                                                              h->npad, (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
     }
 }
 
@@ -767,9 +769,9 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(KP);
     hipFuncSetAttribute((const void *)xprod16_tn_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16, lda, Y16 ? Y16 : h->Y16, ldy, Cx ? Cx : h->Cx, ldc,
-                                                                    slab_stride ? slab_stride : (size_t)KP * ldc, p.stage_begin, p.stage_end, p.sps,
-                                                                    h->scal_exp);
+    xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
+                                                                    (Cx ? Cx : h->Cx) + p.col_off, ldc, slab_stride ? slab_stride : (size_t)KP * ldc,
+                                                                    p.stage_begin, p.stage_end, p.sps, h->scal_exp);
 }
 // split copy of the fixed factor, scaled by its own power of two (two small kernels, outside the cross product's timing
 // scope).  Measured: making these faster (2-D absmax grid, no memset) or moving sweep_consts_kernel to the Gram stream
@@ -855,7 +857,8 @@ static void launch_xprod_tn_rows(nnlm_handle *h, const T *Amat, int lda, const T
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(16 * NKQ);
     hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    xprod_tn_kernel<T, NKQ, 0><<<grid, XPROD_THREADS, lds, h->stream>>>(Amat, lda, Y, ldy, C, ldc, slab_stride, p.stage_begin, p.stage_end, p.sps);
+    xprod_tn_kernel<T, NKQ, 0><<<grid, XPROD_THREADS, lds, h->stream>>>(Amat + (size_t)p.col_off * lda, lda, Y, ldy, C + p.col_off, ldc, slab_stride,
+                                                                         p.stage_begin, p.stage_end, p.sps);
 }
 
 template <typename T>
@@ -1106,8 +1109,9 @@ static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 template <typename T, int EPT>
 static void launch_kl_m(int method, const KlArgs &a, hipStream_t s)
 {
-    if (method == 3) kl_update_kernel<T, EPT, 3><<<a.ncols, KL_THREADS, 0, s>>>(a);
-    else kl_update_kernel<T, EPT, 4><<<a.ncols, KL_THREADS, 0, s>>>(a);
+    if (a.ncols <= a.col0) return;
+    if (method == 3) kl_update_kernel<T, EPT, 3><<<a.ncols - a.col0, KL_THREADS, 0, s>>>(a);
+    else kl_update_kernel<T, EPT, 4><<<a.ncols - a.col0, KL_THREADS, 0, s>>>(a);
 }
 
 template <typename T>
@@ -1157,7 +1161,8 @@ static bool kl_tile_fits(int p, int k, int mw_masked)
 static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
 {
     const int e = kl_tile_ept4(ta.p), C = kl_tile_cols(e);
-    const int nb = (ta.ncols + C - 1) / C;
+    const int nb = (ta.ncols - ta.colbase + C - 1) / C;
+    if (nb <= 0) return;
     const size_t lds = kl_tile_lds_bytes(ta.p, ta.k, C, ta.mask ? ta.mw : 0);
     switch (e) {
     case 1: launch_kl_tile_m<1, 8>(method, ta, nb, lds, s); break;
@@ -1175,25 +1180,55 @@ template <typename T>
 static void launch_kl_stream(int method, const KlArgs &a, int mw, void *st, size_t ldst, hipStream_t s)
 {
     const size_t lds = (size_t)(a.k + 24) * 8;
+    if (a.ncols <= a.col0) return;
     if (method == 3) {
         hipFuncSetAttribute((const void *)kl_stream_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        kl_stream_kernel<T, 3><<<a.ncols, 256, lds, s>>>(a, mw, (T *)st, ldst);
+        kl_stream_kernel<T, 3><<<a.ncols - a.col0, 256, lds, s>>>(a, mw, (T *)st, ldst);
     } else {
         hipFuncSetAttribute((const void *)kl_stream_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        kl_stream_kernel<T, 4><<<a.ncols, 256, lds, s>>>(a, mw, (T *)st, ldst);
+        kl_stream_kernel<T, 4><<<a.ncols - a.col0, 256, lds, s>>>(a, mw, (T *)st, ldst);
     }
 }
 
 template <int NKQ>
 static void launch_colsolve_m(int method, const SweepArgs &a, size_t g_stride, hipStream_t s)
 {
-    const int nb = (a.ncols + 3) / 4;
+    const int nb = (a.ncols - a.col0 + 3) / 4;
+    if (nb <= 0) return;
     if (method == 1) colsolve_ls_kernel<NKQ, 1><<<nb, 256, 0, s>>>(a, g_stride);
     else colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
 }
 
+// F32 mode, SCD: colsolve_fast_kernel (scaled rows of G, six instructions per coordinate); NNLM_COLSOLVE_FAST=0 for A/B runs
+template <int NKQ>
+static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStream_t s)
+{
+    const int nb = (a.ncols - a.col0 + 3) / 4;
+    if (nb <= 0) return;
+    if (a.mask) colsolve_fast_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
+    else colsolve_fast_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
+}
+static bool colsolve_fast_ok(const nnlm_handle *h, int method)
+{
+    static int on = getenv("NNLM_COLSOLVE_FAST") ? atoi(getenv("NNLM_COLSOLVE_FAST")) : 1;
+    return on && method == 1 && h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX;
+}
+static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_stride)
+{
+    switch (h->NKQ) {
+    case 1: launch_colsolve_fast_m<1>(a, g_stride, h->stream); break;
+    case 2: launch_colsolve_fast_m<2>(a, g_stride, h->stream); break;
+    case 3: launch_colsolve_fast_m<3>(a, g_stride, h->stream); break;
+    default: launch_colsolve_fast_m<4>(a, g_stride, h->stream); break;
+    }
+}
+
 static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
 {
+    if (colsolve_fast_ok(h, method)) {
+        launch_colsolve_fast(h, a, g_stride);
+        return;
+    }
     switch (h->NKQ) {
     case 1: launch_colsolve_m<1>(method, a, g_stride, h->stream); break;
     case 2: launch_colsolve_m<2>(method, a, g_stride, h->stream); break;
@@ -1234,34 +1269,36 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
     return NNLM_OK;
 }
 
-// NNLM_NA_GRAM=valu keeps the VALU kernel (A/B)
-static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols)
+// NNLM_NA_GRAM=valu keeps the VALU kernel (A/B).  Per-column Grams of columns [c0, c1) (row lists exist for all ncols columns)
+static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols, int c0, int c1)
 {
     static int use_mfma = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "valu") == 0) ? 0 : 1;
+    const int nc = c1 - c0;
+    if (nc <= 0) return NNLM_OK;
     if (generic_rank(h)) { // rank > 64: k_generic.h
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
         const int lds = 16 * h->KP * 8;
-        na_gram_generic_kernel<<<ncols, 256, lds, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->Graw, h->Gcols);
+        na_gram_generic_kernel<<<nc, 256, lds, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->Graw, h->Gcols, c0);
         return NNLM_OK;
     }
     if (use_mfma) {
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
-        const int nb = (ncols + 3) / 4;
+        const int nb = (nc + 3) / 4;
         switch (h->NKQ) {
-        case 1: na_gram_mfma_kernel<1><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
-        case 2: na_gram_mfma_kernel<2><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
-        case 3: na_gram_mfma_kernel<3><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
-        default: na_gram_mfma_kernel<4><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, ncols); break;
+        case 1: na_gram_mfma_kernel<1><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
+        case 2: na_gram_mfma_kernel<2><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
+        case 3: na_gram_mfma_kernel<3><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
+        default: na_gram_mfma_kernel<4><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
         }
         return NNLM_OK;
     }
     switch (h->NKQ) {
-    case 1: na_gram_kernel<1><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
-    case 2: na_gram_kernel<2><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
-    case 3: na_gram_kernel<3><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
-    default: na_gram_kernel<4><<<ncols, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols); break;
+    case 1: na_gram_kernel<1><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
+    case 2: na_gram_kernel<2><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
+    case 3: na_gram_kernel<3><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
+    default: na_gram_kernel<4><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
     }
     return NNLM_OK;
 }
@@ -1275,12 +1312,43 @@ static void swap_w(nnlm_handle *h)
     h->Wop = h->Wopb[h->wcur];
 }
 
+// Phases of a sharded half-step (test hooks drive virtual ranks phase by phase; production runs PH_ALL):
+//   PH_A   cross product + Gram over this rank's contraction slab, folded into the [G | C] buffer (before the all-reduce)
+//   PH_B   sweep of this rank's columns into the packed slab (after the all-reduce, before the all-gather)
+//   PH_C   unpack of the all-gathered slabs into the resident layouts
+enum { PH_ALL = 0, PH_A = 1, PH_B = 2, PH_C = 3 };
+static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
+                           int nslabs, bool speculative, int phase, bool colshard = false);
+
+static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out);
+static int pack_gather_unpack(nnlm_handle *h, int which, int phase);
+
+// Columns of the factor being solved that this rank sweeps (multi-GPU): equal slabs of cpr columns (multiple of 256).
+struct ShardCols {
+    int cpr, col0, col1;
+};
+static ShardCols shard_cols(const nnlm_handle *h, int ncols)
+{
+    ShardCols c;
+    c.cpr = round_up_i((ncols + h->nranks - 1) / h->nranks, 256); // (a whole number of cross-product tiles in both orientations)
+    c.col0 = h->rank * c.cpr < ncols ? h->rank * c.cpr : ncols;
+    c.col1 = c.col0 + c.cpr < ncols ? c.col0 + c.cpr : ncols;
+    return c;
+}
+
 static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols);
 
+// Across GPUs the KL methods shard by columns of the factor being solved (the solvers need a column's whole contraction and
+// exchange nothing while they run): a rank solves its columns into the packed slab, ONE all-gather returns the factor.
 static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
-                        bool speculative)
+                        bool speculative, int phase)
 {
-    if (h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "KL methods are not sharded across GPUs in this build");
+    if (h->sharded && phase == PH_A) return NNLM_OK; // (test hooks: nothing to all-reduce)
+    if (h->sharded && phase == PH_C) {
+        int rc = pack_gather_unpack(h, which, phase);
+        if (rc == NNLM_OK && which == 0 && !speculative) swap_w(h);
+        return rc;
+    }
     KlArgs a;
     a.k = h->k;
     a.r0 = reg[0];
@@ -1307,6 +1375,21 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         a.op = h->Wopb[h->wcur ^ 1]; a.op_mode = (h->prec == NNLM_PREC_F64) ? 0 : 1; a.op_ld = h->npad;
     }
     const int ld_con = (which == 1) ? h->npad : h->mpad; // padded contraction length
+    const int ncols_all = a.ncols;
+    a.ldo = a.ldx;
+    if (h->sharded) { // this rank's columns only, into the packed slab; the unpack writes masters and operands
+        ShardCols sc;
+        int rcp = pack_prepare(h, ncols_all, &sc);
+        if (rcp != NNLM_OK) return rcp;
+        a.col0 = sc.col0;
+        a.ncols = sc.col1;
+        a.Xout = h->pack_send;
+        a.ldo = sc.cpr;
+        a.ocol0 = sc.col0;
+        a.op = nullptr;
+        a.op_mode = 0;
+    }
+    {
     ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
     if (h->prec == NNLM_PREC_F32 && kl_tile_fits(a.p, h->k, a.mask ? h->MW : 0)) {
         // ---- fp32-operand mode: register-resident state, rows of the fixed factor staged through LDS (kl_tile_kernel) ----
@@ -1341,6 +1424,9 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ta.X = a.X;
         ta.Xout = a.Xout;
         ta.ldx = a.ldx;
+        ta.colbase = a.col0;
+        ta.ldo = a.ldo;
+        ta.ocol0 = a.ocol0;
         kl_sumw_kernel<<<h->k, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->klsw);
         ta.sumw = h->klsw;
         ta.sumw_cols = nullptr;
@@ -1349,11 +1435,11 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
             const int big = h->npad > h->mpad ? h->npad : h->mpad;
             if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
             if (!h->klsw_cols) HIPCHK(h, hipMalloc(&h->klsw_cols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * 8));
-            int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, a.ncols);
+            int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, ncols_all);
             if (rc != NNLM_OK) return rc;
             factor_rows_kernel<<<(a.p + 255) / 256, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->KP, h->Yrow);
-            kl_sumw_cols_kernel<<<(a.ncols + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
-                                                                         h->klsw, h->klsw_cols, h->KP, a.ncols);
+            kl_sumw_cols_kernel<<<(ncols_all + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
+                                                                           h->klsw, h->klsw_cols, h->KP, ncols_all);
             ta.sumw_cols = h->klsw_cols;
         }
         ta.r0 = reg[0];
@@ -1372,7 +1458,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         launch_kl<double>(method, a, h->stream); // strict mode, state in registers
     } else {
         // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel) ----
-        const size_t need = (size_t)a.ncols * 2 * ld_con * esize(h);
+        const size_t need = (size_t)ncols_all * 2 * ld_con * esize(h);
         if (h->klst_bytes < need) {
             hipFree(h->klst);
             h->klst = nullptr;
@@ -1383,18 +1469,16 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         if (h->prec == NNLM_PREC_F64) launch_kl_stream<double>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
         else launch_kl_stream<float>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
     }
+    }
     HIPCHK(h, hipGetLastError());
+    if (h->sharded) {
+        if (phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
+        int rc = pack_gather_unpack(h, which, phase);
+        if (rc != NNLM_OK) return rc;
+    }
     if (which == 0 && !speculative) swap_w(h);
     return NNLM_OK;
 }
-
-// Phases of a sharded half-step (test hooks drive virtual ranks phase by phase; production runs PH_ALL):
-//   PH_A   cross product + Gram over this rank's contraction slab, folded into the [G | C] buffer (before the all-reduce)
-//   PH_B   sweep of this rank's columns into the packed slab (after the all-reduce, before the all-gather)
-//   PH_C   unpack of the all-gathered slabs into the resident layouts
-enum { PH_ALL = 0, PH_A = 1, PH_B = 2, PH_C = 3 };
-static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
-                           int nslabs, bool speculative, int phase);
 
 // speculative (W half-step only): the result goes to the alternate W buffers and the alternate sweep counter and is
 // NOT made current; the caller accepts it later with swap_w() / sw_active ^= 1, or simply drops it.
@@ -1409,20 +1493,41 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     h->sg_prev = sg_which;
     h->sg_which = h->sg_other = -1;
     h->sg_request = false;
-    if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative);
-    if (h->any_missing && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "matrices with missing entries are not sharded across GPUs in this build");
     if (generic_rank(h) && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d is not sharded across GPUs in this build", NNLM_KQ_MAX);
     if (partial_only) phase = PH_A;
-    if (phase == PH_B || phase == PH_C) {
+    if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative, phase);
+    // Missing values across GPUs: every column has a Gram of its own, so the column is the unit: a rank forms the
+    // cross product of ITS columns over the whole contraction, their Grams, solves them, and ONE all-gather returns the factor --
+    // no all-reduce.  Test hooks: phase 1 is empty, phase 2 computes and packs, phase 3 unpacks.
+    const bool colshard = h->sharded && h->any_missing;
+    if (colshard && phase == PH_A) return NNLM_OK;
+    if (phase == PH_C || (phase == PH_B && !colshard)) {
         const HalfPlan pp = plan_half(h, which, h->rank, h->nranks);
-        return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, pp.S, speculative, phase);
+        return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, pp.S, speculative, phase, colshard);
     }
     if (h->any_missing && !h->Gcols) { // NA path workspaces, on first use
         const int big = h->npad > h->mpad ? h->npad : h->mpad;
         HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
         HIPCHK(h, hipMalloc(&h->Gcols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * h->KP * 8));
     }
-    const HalfPlan p = plan_half(h, which, h->rank, h->nranks);
+    HalfPlan p = plan_half(h, which, colshard ? 0 : h->rank, colshard ? 1 : h->nranks);
+    if (colshard) { // own columns only, whole contraction
+        const ShardCols sc = shard_cols(h, (which == 1) ? h->m : h->n);
+        const int tile = (which == 1 || h->x16) ? XPROD_TN_BJ : 64 * (16 / (int)esize(h));
+        p.col_off = sc.col0;
+        p.tiles_x = (sc.col1 - sc.col0 + tile - 1) / tile;
+        if (p.tiles_x > 0) split_plan(p.tiles_x, p.stage_end - p.stage_begin, &p.S, &p.sps);
+        const size_t need = (size_t)p.S * h->KP * ((which == 1) ? h->mpad : h->npad);
+        if (need > h->Cx_elems) { // (fewer tiles -> deeper split-K than the single-GPU plan the slabs were sized for)
+            sync_all(h);
+            hipFree(h->Cx);
+            h->Cx = nullptr;
+            h->Cx_elems = 0;
+            HIPCHK(h, hipMalloc(&h->Cx, need * 8));
+            HIPCHK(h, hipMemset(h->Cx, 0, need * 8));
+            h->Cx_elems = need;
+        }
+    }
     // Dense SCD half-step of the split-fp16 mode on ONE stream (NNLM_ONE_STREAM=0: the two-stream flow below).  The small
     // kernels between a sweep and the next cross product cost as much as they overlap (kernel timeline: 47 us from sweep end
     // to cross product start, 24 us from its end to the next sweep, a third of it cross-stream event latency), so they are
@@ -1501,7 +1606,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HIPCHK(h, hipStreamWaitEvent(h->stream_g, h->ev_factor, 0));
     // 1. cross product slabs
     if (h->x16) prepare_factor16(h, which);
-    {
+    if (p.tiles_x > 0) {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
         if (generic_rank(h)) {
             int rcx = launch_xprod_generic(h, which, p);
@@ -1526,7 +1631,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HIPCHK(h, hipEventRecord(h->ev_gram, h->stream_g));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gram, 0));
     // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer; ONE all-reduce sums it over ranks
-    if (h->sharded) {
+    if (h->sharded && !colshard) {
         const int ld = (which == 1) ? h->mpad : h->npad;
         const size_t cnt = (size_t)h->KP * ld;
         slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, p.S, cnt, h->red + (size_t)h->KP * h->KP);
@@ -1536,20 +1641,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
         }
     }
-    return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase);
-}
-
-// Columns of the factor being solved that this rank sweeps (multi-GPU): equal slabs of cpr columns (multiple of 64).
-struct ShardCols {
-    int cpr, col0, col1;
-};
-static ShardCols shard_cols(const nnlm_handle *h, int ncols)
-{
-    ShardCols c;
-    c.cpr = round_up_i((ncols + h->nranks - 1) / h->nranks, 64);
-    c.col0 = h->rank * c.cpr < ncols ? h->rank * c.cpr : ncols;
-    c.col1 = c.col0 + c.cpr < ncols ? c.col0 + c.cpr : ncols;
-    return c;
+    return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase, colshard);
 }
 
 static int shard_unpack(nnlm_handle *h, int which)
@@ -1569,9 +1661,42 @@ static int shard_unpack(nnlm_handle *h, int which)
     return NNLM_OK;
 }
 
+// packed slab [KP][cpr] this rank solves its columns into (zeroed) and the gathered [nranks][KP][cpr]
+static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out)
+{
+    const ShardCols sc = shard_cols(h, ncols);
+    const size_t need = (size_t)h->KP * sc.cpr;
+    if (h->pack_elems < need * h->nranks) {
+        hipFree(h->pack_send);
+        hipFree(h->pack_all);
+        h->pack_send = h->pack_all = nullptr;
+        h->pack_elems = 0;
+        HIPCHK(h, hipMalloc(&h->pack_send, need * 8));
+        HIPCHK(h, hipMalloc(&h->pack_all, need * h->nranks * 8));
+        h->pack_elems = need * h->nranks;
+    }
+    HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+    *out = sc;
+    return NNLM_OK;
+}
+// ONE ncclAllGather of the packed slabs, then every rank writes masters and GEMM operands of all columns
+static int pack_gather_unpack(nnlm_handle *h, int which, int phase)
+{
+    const int ncols = (which == 1) ? h->m : h->n;
+    const ShardCols sc = shard_cols(h, ncols);
+    if (h->comm) {
+        ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->KP * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    } else if (phase == PH_ALL)
+        return fail(h, NNLM_ERR_COMM, "virtual rank %d of %d has no communicator: drive it with nnlm_debug_phase()", h->rank, h->nranks);
+    return shard_unpack(h, which);
+}
+
 // 3. per-column solve (+ multi-GPU: all-gather of the solved column slabs and unpack into the resident layouts)
+// colshard: the cross product was formed over the whole contraction for this rank's columns only (missing values: per-column
+// Grams make the column the natural unit) -- its split-K slabs are read directly, nothing was all-reduced.
 static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
-                           int nslabs, bool speculative, int phase)
+                           int nslabs, bool speculative, int phase, bool colshard)
 {
     const int ncols = (which == 1) ? h->m : h->n;
     if (phase != PH_C) {
@@ -1579,8 +1704,8 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         SweepArgs a;
         a.Graw = h->Graw;
         a.KPg = h->KP;
-        a.Cx = h->sharded ? h->red + (size_t)h->KP * h->KP : h->Cx;
-        a.nslabs = h->sharded ? 1 : nslabs;
+        a.Cx = (h->sharded && !colshard) ? h->red + (size_t)h->KP * h->KP : h->Cx;
+        a.nslabs = (h->sharded && !colshard) ? 1 : nslabs;
         a.k = h->k;
         a.r0 = reg[0];
         a.r1 = reg[1];
@@ -1621,17 +1746,9 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         }
         a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
         if (h->sharded) { // sweep only this rank's columns into the packed slab; the unpack writes masters and operands
-            const ShardCols sc = shard_cols(h, ncols);
-            const size_t need = (size_t)h->KP * sc.cpr;
-            if (h->pack_elems < need * h->nranks) {
-                hipFree(h->pack_send);
-                hipFree(h->pack_all);
-                h->pack_send = h->pack_all = nullptr;
-                HIPCHK(h, hipMalloc(&h->pack_send, need * 8));
-                HIPCHK(h, hipMalloc(&h->pack_all, need * h->nranks * 8));
-                h->pack_elems = need * h->nranks;
-            }
-            HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+            ShardCols sc;
+            int rcp = pack_prepare(h, ncols, &sc);
+            if (rcp != NNLM_OK) return rcp;
             a.col0 = sc.col0;
             a.ncols = sc.col1;
             a.Xout = h->pack_send;
@@ -1647,7 +1764,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             const int ldy = (which == 1) ? h->npad : h->mpad;
             factor_rows_kernel<<<(p_len + 255) / 256, 256, 0, h->stream>>>(Ymaster, ldy, p_len, h->KP, h->Yrow);
             {
-                int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, a.ncols);
+                int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, ncols, a.col0, a.ncols);
                 if (rcg != NNLM_OK) return rcg;
             }
             a.Graw = h->Gcols;
@@ -1670,13 +1787,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         if (h->sharded && phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
     }
     if (h->sharded) {
-        const ShardCols sc = shard_cols(h, ncols);
-        if (h->comm) {
-            ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->KP * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream);
-            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-        } else if (phase == PH_ALL)
-            return fail(h, NNLM_ERR_COMM, "virtual rank %d of %d has no communicator: drive it with nnlm_debug_phase()", h->rank, h->nranks);
-        int rc = shard_unpack(h, which);
+        int rc = pack_gather_unpack(h, which, phase);
         if (rc != NNLM_OK) return rc;
     }
     if (which == 0 && !speculative) swap_w(h);
@@ -2003,6 +2114,21 @@ extern "C" int nnlm_shard_range(int n, int m, int precision, int which, int rank
     if (c0 > c1) c0 = c1;
     *begin = c0;
     *end = c1;
+    return NNLM_OK;
+}
+
+// Columns [col0, col1) of the factor being solved that `rank` of `nranks` sweeps, and the slab width cpr of the all-gather
+// (every rank sends [k][cpr]).  Pure function of the sizes.
+extern "C" int nnlm_shard_cols(int ncols, int rank, int nranks, int *cpr, int *col0, int *col1)
+{
+    if (ncols < 1 || nranks < 1 || rank < 0 || rank >= nranks || !cpr || !col0 || !col1) return fail(nullptr, NNLM_ERR_ARG, "nnlm_shard_cols: bad arguments");
+    nnlm_handle t;
+    t.rank = rank;
+    t.nranks = nranks;
+    const ShardCols sc = shard_cols(&t, ncols);
+    *cpr = sc.cpr;
+    *col0 = sc.col0;
+    *col1 = sc.col1;
     return NNLM_OK;
 }
 

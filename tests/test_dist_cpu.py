@@ -1,8 +1,10 @@
-"""World-size-2 gloo test of the multi-GPU path's shard arithmetic on CPU (no GPU needed).
+"""World-size-2 gloo test of the multi-GPU path's exchange on CPU (no GPU needed).
 
-GPU side (nnlm_amd/csrc/nnlm_mi355x.hip half_step): each rank contracts the slab nnlm_shard_range() gives it, folds its
-split-K slabs into one [Gram | cross-product] buffer, ONE ncclAllReduce sums it, the sweep runs replicated.  Here the
-same partition function drives a numpy/gloo restatement, and the result must equal the unsharded oracle."""
+GPU side (nnlm_amd/csrc/nnlm_mi355x.hip half_step / half_step_solve / half_step_kl): dense square-loss half-steps =
+contraction-sharded [Gram | cross-product] partials -> ONE ncclAllReduce -> column-sharded solve into packed [k][cpr] slabs ->
+ONE ncclAllGather -> unpack; missing values and KL methods = column-sharded work over the whole contraction -> all-gather ->
+unpack.  tests/dist_worker.py runs exactly that exchange with torch.distributed/gloo, taking every range from the product's own
+partition functions (nnlm_shard_range, nnlm_shard_cols through the C ABI); the results must equal the unsharded oracle."""
 import os
 import socket
 import subprocess
@@ -30,19 +32,35 @@ def test_shard_ranges_partition_the_contraction():
                     assert all(b <= e for b, e in r)
 
 
-def test_two_rank_sharded_half_steps_equal_unsharded_oracle(tmp_path):
+def test_shard_cols_partition_the_columns():
+    for ncols in (20000, 10000, 300, 170, 5, 257, 1):
+        for world in (1, 2, 3, 4, 8):
+            r = [_lib.shard_cols(ncols, rk, world) for rk in range(world)]
+            cpr = r[0][0]
+            assert all(x[0] == cpr for x in r) and cpr % 256 == 0 and cpr * world >= ncols
+            assert r[0][1] == 0 and max(x[2] for x in r) == ncols
+            for rk, (_, c0, c1) in enumerate(r):
+                assert c0 == min(rk * cpr, ncols) and c1 == min(c0 + cpr, ncols)  # rank rk's slab starts at rk * cpr: what the unpack assumes
+
+
+def _run_workers(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "res")
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out], env=env))
     for p in procs:
-        assert p.wait(timeout=300) == 0
-    z0, z1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+        assert p.wait(timeout=600) == 0
+    return [np.load(out + f".rank{r}.npz") for r in range(world)]
+
+
+def test_two_rank_sharded_half_steps_equal_unsharded_oracle(tmp_path):
+    zs = _run_workers(tmp_path, 2)
+    z0, z1 = zs
     rng = np.random.default_rng(42)
     n, m, k = 300, 170, 6
     A = rng.random((n, m))
@@ -52,9 +70,21 @@ def test_two_rank_sharded_half_steps_equal_unsharded_oracle(tmp_path):
         for method in (1, 2):
             Wn_ref, it0 = ref.update(Wt, H, A.T.copy(), None, reg, 4, 1e-9, method)
             Hn_ref, it1 = ref.update(H, Wn_ref, A, None, reg, 4, 1e-9, method)
-            for z in (z0, z1):
+            for z in zs:
                 assert relF(z[f"W_{prec}_{method}"], Wn_ref) < 1e-11 and relF(z[f"H_{prec}_{method}"], Hn_ref) < 1e-11
-                assert list(z[f"it_{prec}_{method}"]) == [it0, it1]
-            # both ranks hold bit-identical factors after the all-reduce (replicated sweep)
+                assert list(z[f"it_{prec}_{method}"]) == [it0, it1]  # per-rank sweep counts, summed by the integer all-reduce
+            # both ranks hold bit-identical factors after the all-gather; each contracted and solved a different share
             assert np.array_equal(z0[f"W_{prec}_{method}"], z1[f"W_{prec}_{method}"])
+            assert np.array_equal(z0[f"H_{prec}_{method}"], z1[f"H_{prec}_{method}"])
             assert not np.array_equal(z0[f"rng_{prec}_{method}"], z1[f"rng_{prec}_{method}"])
+            assert not np.array_equal(z0[f"cols_{prec}_{method}"], z1[f"cols_{prec}_{method}"])
+    # column-sharded forms: missing values (per-column Grams) and the KL methods
+    Ana = A.copy()
+    Ana.ravel()[np.random.default_rng(7).choice(A.size, A.size // 10, replace=False)] = np.nan
+    for tag, Amat, method, inner in (("na1", Ana, 1, 4), ("na2", Ana, 2, 4), ("kl3", A, 3, 2), ("kl4", A, 4, 2), ("nakl", Ana, 4, 1)):
+        Wn_ref, it0 = ref.update(Wt, H, Amat.T.copy(), None, reg, inner, 1e-9, method)
+        Hn_ref, it1 = ref.update(H, Wn_ref, Amat, None, reg, inner, 1e-9, method)
+        for z in zs:
+            assert relF(z[f"W_{tag}"], Wn_ref) < 1e-11 and relF(z[f"H_{tag}"], Hn_ref) < 1e-11, tag
+            assert list(z[f"it_{tag}"]) == [it0, it1], tag
+        assert np.array_equal(z0[f"W_{tag}"], z1[f"W_{tag}"]) and np.array_equal(z0[f"H_{tag}"], z1[f"H_{tag}"])

@@ -156,7 +156,11 @@ def test_known_profiles_and_masks_stacked_like_reformat_input(monkeypatch, pname
     r = api.finish_nnmf(nnlm_amd.c_nnmf(*args), ctx)
     assert r.W.shape == (n, k + k1 + k2) and r.H.shape == (k + k1 + k2, m)
     assert np.array_equal(r.W[:, k:k + k1], W1) and np.array_equal(r.H[k + k1:], H2)  # fixed profiles untouched
-    assert np.all(r.W[:, :k][mask["W"]] == 0) and np.all(r.H[:k][mask["H"]] == 0)
+    # masked entries of the free blocks keep their (random) initial values bit for bit: the reference leaves the
+    # `init[[mat]][mask[[mat]]] <- 0` of R/misc.R:113 commented out
+    Wi, Hi = args[2], args[3]
+    assert np.array_equal(r.W[:, :k][mask["W"]], Wi[:, :k][mask["W"]]) and np.array_equal(r.H[:k][mask["H"]], Hi[:k][mask["H"]])
+    assert np.array_equal(o.W[:, :k][mask["W"]], Wi[:, :k][mask["W"]])
     assert relF(r.W @ r.H, o.W @ o.H) < tol and relF(r.W, o.W) < 50 * tol and relF(r.H, o.H) < 50 * tol
     assert np.allclose(r.mse, o.mse, rtol=100 * tol, atol=1e-14)
     if pname == "f64":
@@ -200,3 +204,131 @@ def test_rank_selection_by_imputation_matches_oracle(monkeypatch):
         assert abs(r.mse[-1] - o.mse[-1]) < 1e-8 * o.mse[-1]
     assert np.allclose(held, held_o, rtol=1e-6)
     assert int(np.argmin(held)) + 1 == k0
+
+
+# ---- the R glue end to end, on a mock of the R API ------------------------------------------------------------------------
+def _mock_r(tmp_path):
+    """Build pkg/src/r_glue.c + tests/r_stub/mock_r.c against the in-tree libnnlm_mi355x.so and load it."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libmockr.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-std=gnu99", "-O1", "-Wno-cast-function-type", "-I" + os.path.join(root, "tests", "r_stub"),
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "pkg", "src", "r_glue.c"),
+                           os.path.join(root, "tests", "r_stub", "mock_r.c"), "-L" + os.path.join(root, "nnlm_amd"), "-lnnlm_mi355x",
+                           "-Wl,-rpath," + os.path.join(root, "nnlm_amd"), "-o", so])
+    lib = C.CDLL(so)
+    vp = C.c_void_p
+    for name, res, args in (("mock_real", vp, [C.POINTER(C.c_double), C.c_int, C.c_int]), ("mock_lgl", vp, [C.POINTER(C.c_int), C.c_int, C.c_int]),
+                            ("mock_int", vp, [C.c_int]), ("mock_dbl", vp, [C.c_double]), ("mock_elt", vp, [vp, C.c_int]),
+                            ("mock_name", C.c_char_p, [vp, C.c_int]), ("mock_real_ptr", C.POINTER(C.c_double), [vp]),
+                            ("mock_int_value", C.c_int, [vp]), ("mock_length", C.c_long, [vp]), ("mock_nrow", C.c_int, [vp]),
+                            ("mock_ncol", C.c_int, [vp]), ("mock_last_error", C.c_char_p, []), ("mock_last_warning", C.c_char_p, []),
+                            ("mock_printed", C.c_char_p, []), ("mock_dotcall", vp, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+                            ("mock_registered_name", C.c_char_p, [C.c_int]), ("mock_reset", None, [C.c_int])):
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = args
+    lib.mock_load_package()
+    return lib
+
+
+def _sexp_real(lib, a):
+    import ctypes as C
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if a.ndim == 1:
+        a = a.reshape(-1, 1, order="F")
+    return lib.mock_real(a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], a.shape[1])
+
+
+def _sexp_lgl(lib, a, shape):
+    import ctypes as C
+    if a is None:
+        return lib.mock_lgl(None, shape[0], 0) if shape[1] == 0 else lib.mock_lgl(None, 0, shape[1])
+    a = np.asfortranarray(np.asarray(a, dtype=np.int32))
+    return lib.mock_lgl(a.ctypes.data_as(C.POINTER(C.c_int)), a.shape[0], a.shape[1])
+
+
+def _dotcall(lib, name, sexps):
+    import ctypes as C
+    arr = (C.c_void_p * len(sexps))(*sexps)
+    return lib.mock_dotcall(name.encode(), len(sexps), arr)
+
+
+def _mat(lib, s):
+    n, m = lib.mock_nrow(s), lib.mock_ncol(s)
+    return np.ctypeslib.as_array(lib.mock_real_ptr(s), shape=(n * m,)).reshape((n, m), order="F").copy()
+
+
+def test_r_glue_end_to_end_with_a_mock_r_runtime(monkeypatch, tmp_path):
+    """The .Call boundary itself (reference src/RcppExports.cpp:10-65): registration table, arities, argument order, result
+    list names and order (R/nnmf.R:184 and R/nnlm.R:122 rename BY POSITION), trace truncation, empty matrices = "not given",
+    RNG scope, warning raised after the library returned, R error on a library error, user interrupt -- with the R API
+    mocked (tests/r_stub/mock_r.c) and the MI355X doing the work."""
+    monkeypatch.delenv("NNLM_PRECISION", raising=False)
+    lib = _mock_r(tmp_path)
+    assert lib.mock_registered_count() == 2
+    assert {(lib.mock_registered_name(i), lib.mock_registered_arity(i)) for i in range(2)} == {(b"_NNLM_c_nnlm", 9), (b"_NNLM_c_nnmf", 17)}
+    A, W0, H0 = _problem()
+    n, m, k = 80, 60, 4
+    alpha, beta = [0.01, 0.0, 0.0], [0.0, 0.0, 0.02]
+
+    def nnmf_args(W, H, max_iter=7, rel_tol=-1.0, verbose=0, show_warning=1, trace=2, kk=k):
+        return [_sexp_real(lib, A), lib.mock_int(kk), _sexp_real(lib, W) if W is not None else lib.mock_real(None, n, 0),
+                _sexp_real(lib, H) if H is not None else lib.mock_real(None, 0, m), _sexp_lgl(lib, None, (n, 0)), _sexp_lgl(lib, None, (0, m)),
+                _sexp_real(lib, alpha), _sexp_real(lib, beta), lib.mock_int(max_iter), lib.mock_dbl(rel_tol), lib.mock_int(1),
+                lib.mock_int(verbose), lib.mock_int(show_warning), lib.mock_int(5), lib.mock_dbl(1e-9), lib.mock_int(1), lib.mock_int(trace)]
+
+    # 1. explicit init: same result as the oracle called with the same 17 arguments
+    lib.mock_reset(-1)
+    out = _dotcall(lib, "_NNLM_c_nnmf", nnmf_args(W0, H0))
+    assert out, lib.mock_last_error()
+    o = ref.c_nnmf(A, k, W0, H0, None, None, alpha, beta, 7, -1.0, 1, 0, True, 5, 1e-9, 1, 2)
+    assert [lib.mock_name(out, i) for i in range(7)] == [b"W", b"H", b"mse_error", b"mkl_error", b"target_error", b"average_epoch", b"n_iteration"]
+    assert relF(_mat(lib, lib.mock_elt(out, 0)), o["W"]) < 1e-9 and relF(_mat(lib, lib.mock_elt(out, 1)), o["H"]) < 1e-9
+    ntr = len(o["mse_error"])
+    for i, key in ((2, "mse_error"), (3, "mkl_error"), (4, "target_error"), (5, "average_epoch")):
+        v = lib.mock_elt(out, i)
+        assert lib.mock_length(v) == ntr  # truncated to the used length (src/nnmf.cpp:200-206)
+        assert np.allclose(_mat(lib, v).ravel(), o[key], rtol=1e-9)
+    assert lib.mock_int_value(lib.mock_elt(out, 6)) == 7
+    assert lib.mock_warning_count() == 1 and lib.mock_last_warning() == b"Target tolerance not reached. Try a larger max.iter."
+    assert lib.mock_protect_balance() == 0 and lib.mock_rng_balance() == 0 and lib.mock_rng_draws() == 0
+
+    # 2. empty W / H = default init through R's RNG: W first (n*k draws), then H (k*m) (src/nnmf.cpp:82-98); verbose = 2 prints
+    lib.mock_reset(-1)
+    out = _dotcall(lib, "_NNLM_c_nnmf", nnmf_args(None, None, max_iter=3, show_warning=0, verbose=2))
+    assert out, lib.mock_last_error()
+    assert lib.mock_rng_draws() == n * k + k * m and lib.mock_warning_count() == 0
+    assert b"Iteration" in lib.mock_printed() and b"Rel. Err." in lib.mock_printed()
+    W = _mat(lib, lib.mock_elt(out, 0))
+    assert W.shape == (n, k) and np.all(W >= 0)
+
+    # 3. a library error becomes an R error (BEGIN_RCPP / END_RCPP): method 9 does not exist
+    lib.mock_reset(-1)
+    bad = nnmf_args(W0, H0)
+    bad[15] = lib.mock_int(9)
+    assert not _dotcall(lib, "_NNLM_c_nnmf", bad) and b"method" in lib.mock_last_error()
+    # wrong arity is refused by the registration table, as R does
+    assert not _dotcall(lib, "_NNLM_c_nnmf", bad[:16]) and b"Incorrect number of arguments" in lib.mock_last_error()
+
+    # 4. user interrupt at the third poll (Rcpp::checkUserInterrupt, src/nnmf.cpp:111)
+    lib.mock_reset(2)
+    assert not _dotcall(lib, "_NNLM_c_nnmf", nnmf_args(W0, H0, max_iter=50)) and lib.mock_onintr_count() == 1
+
+    # 5. c_nnlm: 9 arguments, list (coefficient, n_iteration) (src/nnlm.cpp:49-52); the reference's known-answer vector
+    from helpers import kat_case3
+    A2, b3, expected, _ = kat_case3()
+    lib.mock_reset(-1)
+    y = A2 @ b3
+    p = A2.shape[1]
+    out = _dotcall(lib, "_NNLM_c_nnlm", [_sexp_real(lib, A2), _sexp_real(lib, y), _sexp_real(lib, [0.0, 0.0, 0.0]), _sexp_lgl(lib, None, (p, 0)),
+                                         _sexp_real(lib, np.ones((p, 1))), lib.mock_int(10000), lib.mock_dbl(1e-12), lib.mock_int(1), lib.mock_int(1)])
+    assert out, lib.mock_last_error()
+    assert [lib.mock_name(out, i) for i in range(2)] == [b"coefficient", b"n_iteration"]
+    coef = _mat(lib, lib.mock_elt(out, 0)).ravel()
+    assert np.max(np.abs(coef - expected)) < 1.5e-8  # expect_equal's tolerance, tests/testthat/test-nnlm.R:40-43
+    assert lib.mock_int_value(lib.mock_elt(out, 1)) > 0
+    # dimension mismatch is the reference's message (tests/testthat/test-nnlm.R:54)
+    assert not _dotcall(lib, "_NNLM_c_nnlm", [_sexp_real(lib, A2), _sexp_real(lib, y[:-1]), _sexp_real(lib, [0.0, 0.0, 0.0]), _sexp_lgl(lib, None, (p, 0)),
+                                              _sexp_real(lib, np.ones((p, 1))), lib.mock_int(10), lib.mock_dbl(1e-12), lib.mock_int(1), lib.mock_int(1)])
+    assert lib.mock_last_error() == b"Dimensions of x and y do not match."

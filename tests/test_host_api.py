@@ -202,3 +202,22 @@ def test_mse_mkl():
     e = api.mse_mkl(obs, pred)
     assert np.isclose(e["MSE"], (0.25 + 0 + 1) / 3)
     assert np.isnan(api.mse_mkl(np.array([-1.0, 2.0]), np.array([1.0, 2.0]), show_warning=False)["MKL"])
+
+
+def test_r_glue_compiles_against_the_r_api_surface_it_uses(tmp_path):
+    """pkg/src/r_glue.c (the .Call stubs of the drop-in, reference src/RcppExports.cpp:10-65) must compile cleanly as C99 against
+    the R API.  This image has no R: tests/r_stub/ declares exactly the entries the glue uses (test-only).  The (DL_FUNC)
+    casts of the registration table are R's own idiom, hence -Wno-cast-function-type."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["gcc", "-fsyntax-only", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type", "-I" + os.path.join(root, "tests", "r_stub"),
+           "-I" + os.path.join(root, "include"), os.path.join(root, "pkg", "src", "r_glue.c")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the registration table carries the reference's two routines with the reference's arities (src/RcppExports.cpp:56-60)
+    src = open(os.path.join(root, "pkg", "src", "r_glue.c")).read()
+    assert '{"_NNLM_c_nnlm", (DL_FUNC)&_NNLM_c_nnlm, 9}' in src and '{"_NNLM_c_nnmf", (DL_FUNC)&_NNLM_c_nnmf, 17}' in src
+    for f in ("DESCRIPTION", "NAMESPACE", os.path.join("src", "Makevars"), os.path.join("R", "calls.R")):
+        assert os.path.exists(os.path.join(root, "pkg", f)), f
+    ns = open(os.path.join(root, "pkg", "NAMESPACE")).read()
+    assert "useDynLib(NNLM, .registration = TRUE)" in ns and "import(Rcpp)" not in ns
