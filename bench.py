@@ -194,7 +194,6 @@ def main():
         return float(t[0])
 
     run_steps(h, cfg, args.warmup, trace)
-    Ww, Hw = h.get_factors()  # the state both the timed region and the CPU sample start from
     times, mses = [], []
     for _ in range(max(args.repeats, 1)):
         barrier()
@@ -221,8 +220,13 @@ def main():
 
     # GPU mse after `cpu_iters` iterations from the warmed state (what the CPU sample reproduces)
     gpu_check = None
+    Ww = Hw = None
     if args.cpu_iters > 0 and world == 1 and not force_comm:
-        h.set_factors(k, Ww, Hw)
+        # the state the timed region started from, reproduced (the loop is deterministic): the CPU sample starts there too.
+        # (Taken here, not between warm-up and timing: a host round trip there lets the clocks drop before the timed region.)
+        h.set_factors(k, W0, H0)
+        run_steps(h, cfg, args.warmup, trace)
+        Ww, Hw = h.get_factors()
         gpu_check = run_steps(h, cfg, args.cpu_iters, trace)
 
     if rank != 0:

@@ -235,25 +235,16 @@ __device__ static inline float kl_wave_total(float v)
     v += kl_dpp<0x143, 0xC>(0.f, v); // row_bcast31 into rows 2 and 3
     return v;
 }
-__device__ static inline void kl_wait_vmcnt(int n)
-{
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 #define KLT_THREADS 512
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the vector-memory queue, i.e. wait for the
+// row prefetch (LDS-DMA) at every coordinate step.  Each wavefront reads back only LDS slots its own LDS-DMA wrote, after its
+// own s_waitcnt vmcnt, so the barrier has nothing to order there.
+#define KLT_BARRIER()                                        \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("" ::: "memory");                       \
+    } while (0)
 // dynamic LDS of kl_tile_kernel: two row buffers, coordinates and row sums of the C columns, reduction scratch
 // (a staged row is a whole number of 64 x 16-byte wavefront pieces: which pieces exist is then wave-uniform)
 __host__ __device__ static inline int kl_tile_p4(int p) { return ((p + 3) / 4 + 63) / 64 * 64; }
@@ -277,11 +268,11 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     const int col0 = a.colbase + blockIdx.x * C;
     const float tiny = (float)NNLM_TINY;
 
-    // pieces e = 0 .. nlw-1 of a row (float4 slots e * 512 + 64 * wave + lane) belong to this wavefront: it loads them, reads
-    // them back and owns the matching chunks of the state
-    int nlw = 0;
-#pragma unroll
-    for (int e = 0; e < EPT4; e++) nlw += (e * KLT_THREADS + wave * 64 < P4) ? 1 : 0;
+    // Pieces e = 0 .. EPT4-1 of a row (float4 slots e * 512 + 64 * wave + lane) belong to this wavefront: it loads them, reads
+    // them back and owns the matching chunks of the state.  EPT4 = ceil(P4 / 512) exactly (the host picks the instantiation), so
+    // every piece but the last exists for every wavefront and only `last` is a run-time (wave-uniform) condition.
+    const bool last = (EPT4 - 1) * KLT_THREADS + wave * 64 < P4;
+#define KLT_HAS(e_) ((e_) + 1 < EPT4 || last)
     // Slots at or beyond L4 = ld / 4 (only in a row's last piece; the arrays end there) are never loaded: they are zeroed here
     // once in both buffers, their state entries are b = 0, y = 1, so they add nothing and never change.
     const int voff = lane * 16, L4 = (int)(a.lda >> 2);
@@ -289,14 +280,27 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         *(f32x4 *)(kl_smem + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         *(f32x4 *)(kl_smem + (size_t)rowb + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // piece e of row q -> buffer bufsel.  An LDS-DMA instruction costs its wavefront ~100 issue cycles, so the pieces of the NEXT
+    // row are requested one per chunk of pass A (their issue hides behind the other wavefront's arithmetic), not in a burst at
+    // the top of the step where every wavefront of the block would be issuing loads at the same time.
+    // (written as the instruction itself: scalar base address + one per-lane offset register for all pieces, LDS base in M0 --
+    //  the builtin form spent ~10 scalar and vector instructions per piece on 64-bit per-lane addresses)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)kl_smem + (unsigned)wave * 1024u;
+    auto issue_piece = [&](int q, int bufsel, int e) {
+        const unsigned char *src = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024 + (size_t)e * (KLT_THREADS * 16); // wave-uniform
+        const unsigned dst = lds0 + (unsigned)bufsel * (unsigned)rowb + (unsigned)e * (KLT_THREADS * 16);
+        const unsigned long long sp = (unsigned long long)src;
+        const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)sp);
+        const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
+        // (only slots of the LAST piece can lie beyond the end of the arrays: L4 >= 512 (EPT4 - 1) + 64 wave whenever that piece exists)
+        if (e + 1 < EPT4 || e * KLT_THREADS + wave * 64 + lane < L4)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(su), "s"(du) : "memory");
+    };
     auto issue = [&](int q, int bufsel) {
-        const unsigned char *row = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024; // wave-uniform
 #pragma unroll
         for (int e = 0; e < EPT4; e++)
-            if (e < nlw) {
-                if (e * KLT_THREADS + wave * 64 + lane < L4)
-                    glds16(row + (size_t)e * (KLT_THREADS * 16) + voff, kl_smem + (size_t)bufsel * rowb + (size_t)(e * KLT_THREADS + wave * 64) * 16);
-            }
+            if (KLT_HAS(e)) issue_piece(q, bufsel, e);
     };
 
     bool live[C];
@@ -330,14 +334,20 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
 #pragma unroll
         for (int e = 0; e < EPT4; e++) {
             const int idx4 = e * KLT_THREADS + tid;
-            const bool valid = e < nlw && idx4 < L4 && col0 + c < a.ncols;
+            const bool valid = KLT_HAS(e) && idx4 < L4 && col0 + c < a.ncols;
             b[c][e] = valid ? Ac[idx4] : f32x4{0.f, 0.f, 0.f, 0.f};
-            y[c][e] = valid ? Yc[idx4] + tiny : f32x4{1.f, 1.f, 1.f, 1.f};
-            // (a register use right here: otherwise the wait for this load lands at its first use inside the step loop, where
-            //  it would also wait for the row prefetch issued at the top of every step)
-            asm volatile("" : "+v"(b[c][e]));
+            y[c][e] = valid ? Yc[idx4] : f32x4{1.f, 1.f, 1.f, 1.f};
         }
     }
+    // All 4 C EPT4 loads are in flight together; a register use of every one of them HERE (once): otherwise the compiler puts
+    // the wait for these loads at their first use inside the step loop, where it would also drain the row prefetch every step.
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < EPT4; e++) {
+            asm volatile("" : "+v"(b[c][e]), "+v"(y[c][e]));
+            y[c][e] = y[c][e] + tiny;
+        }
     __syncthreads();
     double S[C];
 #pragma unroll
@@ -361,9 +371,10 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
 #pragma unroll
         for (int c = 0; c < C; c++) flag[c] = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
-            issue((q + 1 < k) ? q + 1 : 0, bufsel ^ 1); // next row (row 0 again for a sweep that may follow)
-            kl_wait_vmcnt(nlw);                         // this wavefront's pieces of row q have landed
+            const int qn = (q + 1 < k) ? q + 1 : 0; // next row (row 0 again for a sweep that may follow)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's pieces of row q (requested during step q - 1) have landed
             const unsigned char *rowp = kl_smem + (size_t)bufsel * rowb;
+            const int nbuf = bufsel ^ 1; // free since pass B of step q - 1
             bufsel ^= 1;
             bool doq[C];
             bool anyq = false;
@@ -374,7 +385,10 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 doq[c] = run[c] && !m;
                 anyq = anyq || doq[c];
             }
-            if (!anyq) continue;
+            if (!anyq) {
+                issue(qn, nbuf);
+                continue;
+            }
             double xq[C];
 #pragma unroll
             for (int c = 0; c < C; c++) xq[c] = xs[c * k + q]; // read BEFORE the barrier: thread 0 rewrites it after
@@ -386,12 +400,14 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             // the row element of chunk e + 1 is fetched from LDS while chunk e is processed; the scheduling barrier keeps the
             // compiler from hoisting all EPT4 fetches (and their registers) to the top of the unrolled loop
             auto wload = [&](int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * KLT_THREADS + tid) * 16); };
-            f32x4 wcur = wload(0);
+            f32x4 wq[2]; // (two named registers by the parity of e: no copy per chunk)
+            wq[0] = wload(0);
 #pragma unroll
             for (int e = 0; e < EPT4; e++) {
-                if (e < nlw) { // wave-uniform
-                    const f32x4 w = wcur;
-                    if (e + 1 < EPT4 && e + 1 < nlw) wcur = wload(e + 1);
+                if (KLT_HAS(e)) { // wave-uniform (compile-time true for all but the last piece)
+                    if (e + 1 < EPT4 && KLT_HAS(e + 1)) wq[(e + 1) & 1] = wload(e + 1);
+                    issue_piece(qn, nbuf, e);
+                    const f32x4 w = wq[e & 1];
 #pragma unroll
                     for (int c = 0; c < C; c++) {
                         f32x4 r;
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     const float t = kl_wave_total((acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]));
                     if (lane == 63) red[((par * C + c) * NV + v) * 8 + wave] = t;
                 }
-            __syncthreads();
+            KLT_BARRIER();
             float coef[C];
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -427,8 +443,8 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 double sv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float *rr = red + ((par * C + c) * NV + v) * 8;
-                    sv[v] = (((double)rr[0] + (double)rr[1]) + ((double)rr[2] + (double)rr[3])) + (((double)rr[4] + (double)rr[5]) + ((double)rr[6] + (double)rr[7]));
+                    const float *rr = red + ((par * C + c) * NV + v) * 8; // eight wave totals (fp32, like the totals themselves)
+                    sv[v] = (double)(((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7])));
                 }
                 const double sw = sws[c * k + q];
                 if (METHOD == 4) {
@@ -459,16 +475,15 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 }
             }
             par ^= 1;
-            bool anyc = false;
-#pragma unroll
-            for (int c = 0; c < C; c++) anyc = anyc || coef[c] != 0.f;
-            if (anyc) { // pass B: y += coef * w for every column of the block (coef = 0 leaves a column's state as it is)
-                f32x4 wb = wload(0);
+            { // pass B: y += coef * w for every column of the block, unconditionally (coef = 0 leaves a state as it is: a branch around
+              // the pass makes the compiler copy all state registers where the two paths meet)
+                f32x4 wb[2];
+                wb[0] = wload(0);
 #pragma unroll
                 for (int e = 0; e < EPT4; e++) {
-                    if (e < nlw) { // wave-uniform
-                        const f32x4 w = wb;
-                        if (e + 1 < EPT4 && e + 1 < nlw) wb = wload(e + 1);
+                    if (KLT_HAS(e)) { // wave-uniform
+                        if (e + 1 < EPT4 && KLT_HAS(e + 1)) wb[(e + 1) & 1] = wload(e + 1);
+                        const f32x4 w = wb[e & 1];
 #pragma unroll
                         for (int c = 0; c < C; c++) y[c][e] = __builtin_elementwise_fma(f32x4{coef[c], coef[c], coef[c], coef[c]}, w, y[c][e]); // :106, :143
                     }
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 }
             }
         }
-        __syncthreads(); // xs[] written by thread 0 during this sweep is read by everyone in the next
+        KLT_BARRIER(); // xs[] written by thread 0 during this sweep is read by everyone in the next
         any = false;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -504,6 +519,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         for (int c = 0; c < C; c++) tot += tdone[c];
         if (tot) atomicAdd(a.sweeps, tot);
     }
+#undef KLT_HAS
 }
 
 // sumw[q] = sum_i Y[q][i], i < p (fp64, from the master): sumW of src/update_with_missing.cpp:27

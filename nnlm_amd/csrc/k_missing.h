@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void miss_transpose_kernel(const uint32_t *__r
     missT[(size_t)i * words_j + wj] = out;
 }
 
-// Yrow[c][q] = Y[q][c] for q < KP (fp64), so that a row of the fixed factor is one contiguous 8*KP-byte read.
-__global__ __launch_bounds__(256) void factor_rows_kernel(const double *__restrict__ Y, int ld, int ncols, int KP,
-                                                          double *__restrict__ Yrow)
+// Yrow[c][q] = Y[q][c] for q < KP, so that a row of the fixed factor is one contiguous KP-element read (T = double, or
+// float for the fp32-operand mode's per-column Grams).
+template <typename T = double>
+__global__ __launch_bounds__(256) void factor_rows_kernel(const double *__restrict__ Y, int ld, int ncols, int KP, T *__restrict__ Yrow)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncols) return;
-    for (int q = 0; q < KP; q++) Yrow[(size_t)c * KP + q] = Y[(size_t)q * ld + c];
+    for (int q = 0; q < KP; q++) Yrow[(size_t)c * KP + q] = (T)Y[(size_t)q * ld + c];
 }
 
 // Per-column Gram.  bits: this column's missing mask over the contraction index (p bits, `words` words per
@@ -308,13 +309,19 @@ __global__ __launch_bounds__(256) void na_fill_kernel(const uint32_t *__restrict
     }
 }
 
-template <int NKQ>
+// T = float (fp32-operand mode): the listed rows enter v_mfma_f32_16x16x4_f32 rounded to fp32 (twice the fp64 rate, half the
+// gather bytes), fp32 partial sums are folded into fp64 every 256 rows as in the cross products; the correction
+// sum_missing w w^T is ~the missing fraction of G, so G_j keeps ~1e-8 relative accuracy.  T = double: the strict mode.
+template <typename T, int NKQ>
 __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
-                                                           const double *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
+                                                           const T *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
                                                            int ncols, int col0 = 0)
 {
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
     constexpr int KP = 16 * NKQ;
     constexpr int NP = NKQ * (NKQ + 1) / 2;
+    constexpr bool F32 = sizeof(T) == 4;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int col = col0 + blockIdx.x * 4 + (threadIdx.x >> 6); // columns col0 .. ncols-1
     if (col >= ncols) return; // whole wave
@@ -323,29 +330,44 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
     const bool complement = (mt >> 31) != 0;
     const int *rows = idx + ptr[col];
 
-    f64x4 acc[NP];
+    acc_t acc[NP];
+    f64x4 acc64[F32 ? NP : 1];
 #pragma unroll
-    for (int i = 0; i < NP; i++) acc[i] = f64x4{0, 0, 0, 0};
-    double x[NKQ], xn[NKQ];
-    auto load = [&](int g, double (&dst)[NKQ]) {
+    for (int i = 0; i < NP; i++) acc[i] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < (F32 ? NP : 1); i++) acc64[i] = f64x4{0, 0, 0, 0};
+    T x[NKQ], xn[NKQ];
+    auto load = [&](int g, T (&dst)[NKQ]) {
         const int r = 4 * g + lg;
         const int row = (r < len) ? rows[r] : -1;
 #pragma unroll
-        for (int t = 0; t < NKQ; t++) dst[t] = (row >= 0) ? Yrow[(size_t)row * KP + 16 * t + l15] : 0.0;
+        for (int t = 0; t < NKQ; t++) dst[t] = (row >= 0) ? Yrow[(size_t)row * KP + 16 * t + l15] : (T)0;
     };
     const int ng = (len + 3) / 4;
     if (ng > 0) load(0, x);
+    int since = 0;
     for (int g = 0; g < ng; g++) {
         if (g + 1 < ng) load(g + 1, xn);
         int pi = 0;
 #pragma unroll
         for (int a = 0; a < NKQ; a++)
 #pragma unroll
-            for (int b = a; b < NKQ; b++, pi++) acc[pi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[a], x[b], acc[pi], 0, 0, 0);
+            for (int b = a; b < NKQ; b++, pi++) acc[pi] = M::mma(x[a], x[b], acc[pi]);
 #pragma unroll
         for (int t = 0; t < NKQ; t++) x[t] = xn[t];
+        if constexpr (F32) {
+            if (++since == 64) { // 256 rows
+                since = 0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc64[i][r] += (double)acc[i][r];
+                    acc[i] = acc_t{0, 0, 0, 0};
+                }
+            }
+        }
     }
-    // f64 C/D layout: reg r -> row lg + 4r, col l15; both triangles of the symmetric result
+    // C/D layout: reg r -> row M::row_of(lane, r), col l15; both triangles of the symmetric result
     double *out = Gcols + (size_t)col * KP * KP;
     int pi = 0;
 #pragma unroll
@@ -354,8 +376,11 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
         for (int b = a; b < NKQ; b++, pi++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = 16 * a + lg + 4 * r, j = 16 * b + l15;
-                const double v = complement ? Gfull[i * KP + j] - acc[pi][r] : acc[pi][r];
+                const int i = 16 * a + M::row_of(lane, r), j = 16 * b + l15;
+                double sum;
+                if constexpr (F32) sum = acc64[pi][r] + (double)acc[pi][r];
+                else sum = acc[pi][r];
+                const double v = complement ? Gfull[i * KP + j] - sum : sum;
                 out[i * KP + j] = v;
                 if (a != b) out[j * KP + i] = v;
             }

@@ -1146,11 +1146,8 @@ static void launch_kl_tile_m(int method, const KlTileArgs &ta, int nb, size_t ld
 static int kl_tile_cols(int ept4) { return ept4 <= 2 ? 8 : (ept4 <= 5 ? 4 : 2); }
 static int kl_tile_ept4(int p)
 {
-    const int e = (kl_tile_p4(p) + KLT_THREADS - 1) / KLT_THREADS;
-    const int steps[8] = {1, 2, 3, 4, 5, 6, 8, 10};
-    for (int i = 0; i < 8; i++)
-        if (e <= steps[i]) return steps[i];
-    return 0; // contraction too long for the register-resident kernel
+    const int e = (kl_tile_p4(p) + KLT_THREADS - 1) / KLT_THREADS; // float4 pieces per thread: the instantiation is exact
+    return e <= 10 ? e : 0;                                        // 0: contraction too long for the register-resident kernel
 }
 static bool kl_tile_fits(int p, int k, int mw_masked)
 {
@@ -1171,7 +1168,9 @@ static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
     case 4: launch_kl_tile_m<4, 4>(method, ta, nb, lds, s); break;
     case 5: launch_kl_tile_m<5, 4>(method, ta, nb, lds, s); break;
     case 6: launch_kl_tile_m<6, 2>(method, ta, nb, lds, s); break;
+    case 7: launch_kl_tile_m<7, 2>(method, ta, nb, lds, s); break;
     case 8: launch_kl_tile_m<8, 2>(method, ta, nb, lds, s); break;
+    case 9: launch_kl_tile_m<9, 2>(method, ta, nb, lds, s); break;
     default: launch_kl_tile_m<10, 2>(method, ta, nb, lds, s); break;
     }
 }
@@ -1221,6 +1220,14 @@ static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_st
     case 3: launch_colsolve_fast_m<3>(a, g_stride, h->stream); break;
     default: launch_colsolve_fast_m<4>(a, g_stride, h->stream); break;
     }
+}
+
+// Largest column shard the wave-per-column sweep takes over from the workgroup-specialised one (multi-GPU dense path);
+// NNLM_SWEEP_WAVE_COLS overrides it (0 = never)
+static int sweep_wave_cols_max()
+{
+    static int v = getenv("NNLM_SWEEP_WAVE_COLS") ? atoi(getenv("NNLM_SWEEP_WAVE_COLS")) : 4096;
+    return v;
 }
 
 static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
@@ -1275,6 +1282,12 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
     static int use_mfma = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "valu") == 0) ? 0 : 1;
     const int nc = c1 - c0;
     if (nc <= 0) return NNLM_OK;
+    const double *Ym = (which == 1) ? h->W64 : h->H64; // fixed factor [KP][ldy]; the kernels gather its ROWS: row-major copy Yrow [p][KP]
+    const int ldy = (which == 1) ? h->npad : h->mpad;
+    static int g32 = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "f64") == 0) ? 0 : 1;
+    const bool f32rows = use_mfma && !generic_rank(h) && h->prec == NNLM_PREC_F32 && g32;
+    if (f32rows) factor_rows_kernel<float><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, (float *)h->Yrow);
+    else factor_rows_kernel<double><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, h->Yrow);
     if (generic_rank(h)) { // rank > 64: k_generic.h
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
@@ -1286,11 +1299,23 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
         const int nb = (nc + 3) / 4;
-        switch (h->NKQ) {
-        case 1: na_gram_mfma_kernel<1><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
-        case 2: na_gram_mfma_kernel<2><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
-        case 3: na_gram_mfma_kernel<3><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
-        default: na_gram_mfma_kernel<4><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->Graw, h->Gcols, c1, c0); break;
+        // F32 mode: fp32 copy of the factor rows + v_mfma_f32_16x16x4_f32 (NNLM_NA_GRAM=f64 keeps the fp64 matrix cores for A/B runs)
+        if (f32rows) {
+#define NNLM_NAG(T_, N_) na_gram_mfma_kernel<T_, N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const T_ *)h->Yrow, h->Graw, h->Gcols, c1, c0)
+            switch (h->NKQ) {
+            case 1: NNLM_NAG(float, 1); break;
+            case 2: NNLM_NAG(float, 2); break;
+            case 3: NNLM_NAG(float, 3); break;
+            default: NNLM_NAG(float, 4); break;
+            }
+        } else {
+            switch (h->NKQ) {
+            case 1: NNLM_NAG(double, 1); break;
+            case 2: NNLM_NAG(double, 2); break;
+            case 3: NNLM_NAG(double, 3); break;
+            default: NNLM_NAG(double, 4); break;
+            }
+#undef NNLM_NAG
         }
         return NNLM_OK;
     }
@@ -1760,9 +1785,6 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         if (h->any_missing) {
             // per-column Gram over the finite rows of each column (src/update_with_missing.cpp:90), then the solver
             const int p_len = (which == 1) ? h->n : h->m;
-            const double *Ymaster = (which == 1) ? h->W64 : h->H64;
-            const int ldy = (which == 1) ? h->npad : h->mpad;
-            factor_rows_kernel<<<(p_len + 255) / 256, 256, 0, h->stream>>>(Ymaster, ldy, p_len, h->KP, h->Yrow);
             {
                 int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, ncols, a.col0, a.ncols);
                 if (rcg != NNLM_OK) return rcg;
@@ -1773,6 +1795,10 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                 if (rcs != NNLM_OK) return rcs;
             } else
                 launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
+        } else if (h->sharded && colsolve_fast_ok(h, method) && a.ncols - a.col0 <= sweep_wave_cols_max()) {
+            // a column shard too small to fill the chip's workgroup slots: the workgroup-specialised sweep takes ~0.19 ms however few
+            // columns it gets (2500 steps x ~180 cycles); one wavefront per column takes 2500 steps x ~40 cycles + 38 us per 1000 columns
+            launch_colsolve_fast(h, a, 0);
         } else if (a.ncols > a.col0) {
             int rcs = launch_sweep(h, method, a);
             if (rcs != NNLM_OK) return rcs;

@@ -600,3 +600,88 @@ def test_kl_contraction_longer_than_32768(pname, prec, tol, method):
         W1, _ = h.get_factors()
         Wt_ref, _ = ref.update(W0.T.copy(), H_ref, A.T.copy(), None, reg, 2, 1e-9, method)
         assert relF(W1, Wt_ref.T) < 10 * tol
+
+
+# ---- column-sharded half-steps (missing values, KL methods): all-gather only -------------------------------------------
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["na_scd", "na_lee", "kl_scd", "kl_lee", "na_kl_lee"])
+def test_virtual_ranks_run_column_sharded_half_steps(pname, prec, tol, world, case):
+    """With missing values (per-column Grams) and for the KL methods the column is the unit of the multi-GPU split: a rank does
+    all the work of ITS columns (nnlm_shard_cols) over the whole contraction into a packed slab, ONE all-gather returns the
+    factor, every rank unpacks -- no all-reduce.  `world` virtual ranks on one device, the host standing in for ncclAllGather;
+    every rank must end with identical factors, equal to the single-rank result."""
+    method = {"na_scd": 1, "na_lee": 2, "kl_scd": 3, "kl_lee": 4, "na_kl_lee": 4}[case]
+    rng = np.random.default_rng(world + method)
+    n, m, k = 700, 333, 13
+    A = rng.random((n, 5)) @ rng.random((5, m)) + 0.1 * rng.random((n, m))
+    if case.startswith("na"):
+        A.ravel()[rng.choice(A.size, A.size // 10, replace=False)] = np.nan
+    W0, H0 = 0.3 * rng.random((n, k)), 0.3 * rng.random((k, m))
+    Wm = rng.random((n, k)) < 0.05
+    reg = [0.02, 0.01, 0.03]
+    inner = 5 if method < 3 else 2
+    if method >= 3 and pname == "f32":
+        tol = 1e-4
+    with nnlm_amd.Handle(0, prec) as h1:
+        h1.set_matrix(A)
+        h1.set_factors(k, W0, H0, Wm, None)
+        h1.iterate(2, reg, reg, inner, 1e-9, method)
+        W_ref, H_ref = h1.get_factors()
+        sw_ref = h1.take_sweeps()
+        mse_ref = h1.errors()[0]
+    hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
+    try:
+        for rk, h in enumerate(hs):
+            h.comm_init(None, rk, world)
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0, Wm, None)
+        for _ in range(2):
+            for which in (0, 1):
+                for phase in (1, 2):
+                    for h in hs:
+                        h.debug_phase(which, phase, reg, inner, 1e-9, method)
+                _lib.debug_exchange(hs, which, 2)  # the all-gather (phase 1 left nothing to all-reduce)
+                for h in hs:
+                    h.debug_phase(which, 3, reg, inner, 1e-9, method)
+        res = [h.get_factors() for h in hs]
+        sweeps = sum(h.take_sweeps() for h in hs)
+        mse = sum(h.errors()[0] for h in hs)
+    finally:
+        for h in hs:
+            h.close()
+    for W, H in res[1:]:
+        assert np.array_equal(W, res[0][0]) and np.array_equal(H, res[0][1])
+    # the same kernels on the same columns: only the split-K depth of the cross product differs between the sharded and the
+    # single-rank launch (fewer column tiles per launch), i.e. the order of a few fp64 additions
+    t = 1e-11 if pname == "f64" else tol
+    assert relF(res[0][0], W_ref) < t and relF(res[0][1], H_ref) < t
+    assert np.array_equal(res[0][0][Wm], W0[Wm])
+    assert abs(sweeps - sw_ref) <= (0 if pname == "f64" else 2)
+    assert abs(mse - mse_ref) < (1e-9 if pname == "f64" else 1e-5) * mse_ref
+
+
+@pytest.mark.parametrize("case", ["na_scd", "kl_lee"])
+def test_column_sharded_path_with_a_real_one_rank_rccl_communicator(case):
+    """The same code path end to end with a real RCCL communicator of size 1 (ncclAllGather of the packed slab, unpack)."""
+    method = 1 if case == "na_scd" else 4
+    rng = np.random.default_rng(5)
+    n, m, k = 300, 200, 9
+    A = rng.random((n, m))
+    if case == "na_scd":
+        A.ravel()[rng.choice(A.size, A.size // 10, replace=False)] = np.nan
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    reg = [0.02, 0.01, 0.03]
+    out = []
+    for sharded in (False, True):
+        with nnlm_amd.Handle(0, _lib.PREC_F64) as h:
+            if sharded:
+                h.comm_init(_lib.comm_unique_id(), 0, 1)
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0)
+            r = h.run(reg, reg, 4, -1.0, 0, False, 3, 1e-9, method, 2)
+            W, H = h.get_factors()
+            out.append((W, H, r))
+    a, b = out
+    assert relF(a[0], b[0]) < 1e-12 and relF(a[1], b[1]) < 1e-12
+    assert np.allclose(a[2]["mse_error"], b[2]["mse_error"], rtol=1e-12) and np.array_equal(a[2]["average_epoch"], b[2]["average_epoch"])
