@@ -303,20 +303,19 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             if (KLT_HAS(e)) issue_piece(q, bufsel, e);
     };
 
-    bool live[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        const int col = col0 + c;
-        live[c] = col < a.ncols;
-        if (live[c] && a.mask) { // all coordinates masked: 0 sweeps, values copied through (src/update_with_missing.cpp:33)
-            bool all = true;
-            for (int w = 0; w < a.mw; w++) {
-                const int bits = (k - 64 * w >= 64) ? 64 : k - 64 * w;
-                const unsigned long long km = (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull);
-                all = all && ((a.mask[(size_t)col * a.mw + w] & km) == km);
-            }
-            live[c] = !all;
+    // The scalar part of a coordinate step (sums of the eight wave totals, quotient, new coordinate, rel-change test) is the same
+    // ~50 fp64 instructions for every column: lane c of every wavefront does it for column c (all C columns in ONE instruction
+    // stream, redundantly per wavefront -- no second barrier), the per-column coefficients come back with v_readlane.
+    const int lc = (lane < C) ? lane : 0; // this lane's column of the block
+    bool live_l = col0 + lc < a.ncols;
+    if (live_l && a.mask) { // all coordinates masked: 0 sweeps, values copied through (src/update_with_missing.cpp:33)
+        bool all = true;
+        for (int w = 0; w < a.mw; w++) {
+            const int bits = (k - 64 * w >= 64) ? 64 : k - 64 * w;
+            const unsigned long long km = (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull);
+            all = all && ((a.mask[(size_t)(col0 + lc) * a.mw + w] & km) == km);
         }
+        live_l = !all;
     }
     if (a.mask)
         for (int e = tid; e < C * a.mw; e += KLT_THREADS) mks[e] = (col0 + e / a.mw < a.ncols) ? a.mask[(size_t)col0 * a.mw + e] : ~0ull;
@@ -349,49 +348,30 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             y[c][e] = y[c][e] + tiny;
         }
     __syncthreads();
-    double S[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        S[c] = 0.0;
-        for (int q = 0; q < k; q++) S[c] += xs[c * k + q];
-    }
-
-    unsigned tdone[C];
-    bool run[C], flag[C];
-    bool any = false;
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        tdone[c] = 0;
-        run[c] = live[c] && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol;
-        any = any || run[c];
-    }
+    const unsigned long long cmask = (C >= 64) ? ~0ull : ((1ull << C) - 1ull); // lanes that own a column
+    double S_l = 0.0;
+    for (int q = 0; q < k; q++) S_l += xs[lc * k + q];
+    unsigned tdone_l = 0;
+    bool run_l = live_l && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol, flag_l = false;
+    bool any = (__ballot(run_l) & cmask) != 0ull;
     int par = 0, bufsel = 0;
     if (any) issue(0, 0);
-    while (any) { // block-uniform: everything that decides it is computed redundantly by every thread
-#pragma unroll
-        for (int c = 0; c < C; c++) flag[c] = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
+    while (any) { // block-uniform: every wavefront holds the same per-lane column state
+        flag_l = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
             const int qn = (q + 1 < k) ? q + 1 : 0; // next row (row 0 again for a sweep that may follow)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's pieces of row q (requested during step q - 1) have landed
             const unsigned char *rowp = kl_smem + (size_t)bufsel * rowb;
             const int nbuf = bufsel ^ 1; // free since pass B of step q - 1
             bufsel ^= 1;
-            bool doq[C];
-            bool anyq = false;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                bool m = false;
-                if (a.mask) m = (mks[c * a.mw + (q >> 6)] >> (q & 63)) & 1ull; // (LDS copy: a global load here would drain the row prefetch)
-                doq[c] = run[c] && !m;
-                anyq = anyq || doq[c];
-            }
-            if (!anyq) {
+            bool m_l = false;
+            if (a.mask) m_l = (mks[lc * a.mw + (q >> 6)] >> (q & 63)) & 1ull; // (LDS copy: a global load here would drain the row prefetch)
+            const bool doq_l = run_l && !m_l;
+            if ((__ballot(doq_l) & cmask) == 0ull) { // no column of the block visits this coordinate
                 issue(qn, nbuf);
                 continue;
             }
-            double xq[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) xq[c] = xs[c * k + q]; // read BEFORE the barrier: thread 0 rewrites it after
+            const double xq_l = xs[lc * k + q]; // read BEFORE the barrier: wavefront 0 rewrites it after
             f32x4 acc[C][NV];
 #pragma unroll
             for (int c = 0; c < C; c++)
@@ -435,45 +415,47 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     if (lane == 63) red[((par * C + c) * NV + v) * 8 + wave] = t;
                 }
             KLT_BARRIER();
-            float coef[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                coef[c] = 0.f;
-                if (!doq[c]) continue; // block-uniform
+            float coef_l = 0.f;
+            {
                 double sv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float *rr = red + ((par * C + c) * NV + v) * 8; // eight wave totals (fp32, like the totals themselves)
+                    const float *rr = red + ((par * C + lc) * NV + v) * 8; // eight wave totals (fp32, like the totals themselves)
                     sv[v] = (double)(((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7])));
                 }
-                const double sw = sws[c * k + q];
+                const double sw = sws[lc * k + q];
                 if (METHOD == 4) {
-                    const double den = sw + a.r0 * xq[c] + a.r1 * (S[c] - xq[c]) + a.r2; // :142
+                    const double den = sw + a.r0 * xq_l + a.r1 * (S_l - xq_l) + a.r2; // :142
                     double rd = __builtin_amdgcn_rcp(den);
                     rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
                     const double tmp = sv[0] * rd;
-                    const double d = (tmp - 1) * xq[c]; // :143
-                    coef[c] = (float)d;
-                    S[c] += d;                          // :144
-                    if (tid == 0) xs[c * k + q] = xq[c] * tmp; // :145
-                    flag[c] = flag[c] || (2 * fabs(tmp - 1) > a.rel_tol * (tmp + 1)); // :146-147 without the division
+                    const double d = (tmp - 1) * xq_l; // :143
+                    if (doq_l) {
+                        coef_l = (float)d;
+                        S_l += d;                                                          // :144
+                        if (wave == 0 && lane < C) xs[lc * k + q] = xq_l * tmp;            // :145
+                        flag_l = flag_l || (2 * fabs(tmp - 1) > a.rel_tol * (tmp + 1));    // :146-147 without the division
+                    }
                 } else {
-                    const double aa = sv[0] + a.r0;                                              // :98,100
-                    const double bb = (sv[1] - sw) + aa * xq[c] - a.r2 - a.r1 * (S[c] - xq[c]); // :99,101
+                    const double aa = sv[0] + a.r0;                                             // :98,100
+                    const double bb = (sv[NV - 1] - sw) + aa * xq_l - a.r2 - a.r1 * (S_l - xq_l); // :99,101
                     const double den = aa + NNLM_TINY;
                     double rd = __builtin_amdgcn_rcp(den);
                     rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
                     double tmp = bb * rd; // :102
                     if (!(tmp > 0)) tmp = 0;
-                    if (tmp != xq[c]) {
-                        const double d = tmp - xq[c];
-                        coef[c] = (float)d;
-                        flag[c] = flag[c] || (2 * fabs(d) > a.rel_tol * (tmp + xq[c] + NNLM_TINY)); // :107-108
-                        S[c] += d;
-                        if (tid == 0) xs[c * k + q] = tmp;
+                    if (doq_l && tmp != xq_l) {
+                        const double d = tmp - xq_l;
+                        coef_l = (float)d;
+                        flag_l = flag_l || (2 * fabs(d) > a.rel_tol * (tmp + xq_l + NNLM_TINY)); // :107-108
+                        S_l += d;
+                        if (wave == 0 && lane < C) xs[lc * k + q] = tmp;
                     }
                 }
             }
+            float coef[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) coef[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef_l), c));
             par ^= 1;
             { // pass B: y += coef * w for every column of the block, unconditionally (coef = 0 leaves a state as it is: a branch around
               // the pass makes the compiler copy all state registers where the two paths meet)
@@ -492,15 +474,11 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             }
         }
         KLT_BARRIER(); // xs[] written by thread 0 during this sweep is read by everyone in the next
-        any = false;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            if (run[c]) {
-                tdone[c]++;
-                run[c] = tdone[c] < a.max_iter && flag[c];
-            }
-            any = any || run[c];
+        if (run_l) {
+            tdone_l++;
+            run_l = tdone_l < a.max_iter && flag_l;
         }
+        any = (__ballot(run_l) & cmask) != 0ull;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the row requested for a sweep that did not follow
     __syncthreads();
@@ -513,11 +491,9 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
     }
-    if (tid == 0) {
-        unsigned long long tot = 0;
-#pragma unroll
-        for (int c = 0; c < C; c++) tot += tdone[c];
-        if (tot) atomicAdd(a.sweeps, tot);
+    if (wave == 0) {
+        const long long tot = wave_sum_ll((lane < C) ? (long long)tdone_l : 0ll);
+        if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
     }
 #undef KLT_HAS
 }

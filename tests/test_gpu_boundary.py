@@ -332,3 +332,31 @@ def test_r_glue_end_to_end_with_a_mock_r_runtime(monkeypatch, tmp_path):
     assert not _dotcall(lib, "_NNLM_c_nnlm", [_sexp_real(lib, A2), _sexp_real(lib, y[:-1]), _sexp_real(lib, [0.0, 0.0, 0.0]), _sexp_lgl(lib, None, (p, 0)),
                                               _sexp_real(lib, np.ones((p, 1))), lib.mock_int(10), lib.mock_dbl(1e-12), lib.mock_int(1), lib.mock_int(1)])
     assert lib.mock_last_error() == b"Dimensions of x and y do not match."
+
+
+# ---- bench.py's N > 1 plumbing on a one-GPU box ------------------------------------------------------------------------------
+def test_bench_multi_gpu_branch_runs_with_a_forced_one_rank_communicator(tmp_path):
+    """bench.py --gpus N takes a different path from N = 1: gloo process group, RCCL id broadcast, LOCAL_RANK -> device,
+    nnlm_comm_init, barriers, max over ranks, the sharded half-steps.  No multi-GPU box is available to this suite, so the branch
+    is forced with WORLD_SIZE = 1 (NNLM_BENCH_FORCE_COMM=1: a real RCCL communicator of size 1) on a reduced size and its line
+    is compared with the plain single-GPU line of the same size: same final mse, same JSON contract."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-iters", "0", "--repeats", "1",
+            "--size", "3000,2000,20"]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NNLM_BENCH_FORCE_COMM="1")
+    sharded = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    env.pop("NNLM_BENCH_FORCE_COMM")
+    plain = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    for line in (sharded, plain):
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline"):
+            assert key in line, key
+        assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "strong"
+    assert "all-reduce" in sharded["config"]["parallelism"] and plain["config"]["parallelism"] == "1 GPU"
+    assert abs(sharded["final_mse"] - plain["final_mse"]) < 1e-6 * plain["final_mse"]

@@ -177,4 +177,4 @@ def test_f32_mode_stops_at_the_iteration_the_oracle_stops(seed, shape):
     assert r["warning"] == o["warning"]
     if r["n_iteration"] == o["n_iteration"]:
         assert relF(W @ H, o["W"] @ o["H"]) < 1e-4
-        assert np.allclose(r["target_error"], o["target_error"], rtol=1e-5)
+        assert np.allclose(r["target_error"], o["target_error"], rtol=1e-4)  # (targets ~1e-4 here: fp32 A leaves ~1e-9 absolute)
