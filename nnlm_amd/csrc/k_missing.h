@@ -336,25 +336,39 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
     for (int i = 0; i < NP; i++) acc[i] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < (F32 ? NP : 1); i++) acc64[i] = f64x4{0, 0, 0, 0};
-    T x[NKQ], xn[NKQ];
+    // Tile t, position l15 stands for coordinate NKQ * l15 + t (not 16 t + l15): a lane's NKQ operands are then NKQ CONSECUTIVE
+    // entries of the listed row -- one 16-byte load for NKQ = 4 floats instead of four 4-byte loads 64 bytes apart -- and the Gram
+    // comes out with rows and columns permuted the same way, undone in the index arithmetic of the final store.
+    // Two groups of four rows are in flight ahead of the one being multiplied (the gathers are L2 / MALL latency).
+    T x[NKQ], xn[NKQ], xnn[NKQ];
     auto load = [&](int g, T (&dst)[NKQ]) {
         const int r = 4 * g + lg;
         const int row = (r < len) ? rows[r] : -1;
+        if (row >= 0) {
+            constexpr size_t AL = (NKQ == 3) ? sizeof(T) : NKQ * sizeof(T); // (NKQ = 3: no power-of-two vector)
+            const T *src = (const T *)__builtin_assume_aligned(Yrow + (size_t)row * KP + NKQ * l15, AL);
+            __builtin_memcpy(dst, src, sizeof(T) * NKQ);
+        } else {
 #pragma unroll
-        for (int t = 0; t < NKQ; t++) dst[t] = (row >= 0) ? Yrow[(size_t)row * KP + 16 * t + l15] : (T)0;
+            for (int t = 0; t < NKQ; t++) dst[t] = (T)0;
+        }
     };
     const int ng = (len + 3) / 4;
     if (ng > 0) load(0, x);
+    if (ng > 1) load(1, xn);
     int since = 0;
     for (int g = 0; g < ng; g++) {
-        if (g + 1 < ng) load(g + 1, xn);
+        if (g + 2 < ng) load(g + 2, xnn);
         int pi = 0;
 #pragma unroll
         for (int a = 0; a < NKQ; a++)
 #pragma unroll
             for (int b = a; b < NKQ; b++, pi++) acc[pi] = M::mma(x[a], x[b], acc[pi]);
 #pragma unroll
-        for (int t = 0; t < NKQ; t++) x[t] = xn[t];
+        for (int t = 0; t < NKQ; t++) {
+            x[t] = xn[t];
+            xn[t] = xnn[t];
+        }
         if constexpr (F32) {
             if (++since == 64) { // 256 rows
                 since = 0;
@@ -367,7 +381,8 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
             }
         }
     }
-    // C/D layout: reg r -> row M::row_of(lane, r), col l15; both triangles of the symmetric result
+    // C/D layout: reg r -> tile row M::row_of(lane, r), tile column l15, i.e. coordinates (NKQ row + a, NKQ l15 + b); both
+    // triangles of the symmetric result
     double *out = Gcols + (size_t)col * KP * KP;
     int pi = 0;
 #pragma unroll
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
         for (int b = a; b < NKQ; b++, pi++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = 16 * a + M::row_of(lane, r), j = 16 * b + l15;
+                const int i = NKQ * M::row_of(lane, r) + a, j = NKQ * l15 + b;
                 double sum;
                 if constexpr (F32) sum = acc64[pi][r] + (double)acc[pi][r];
                 else sum = acc[pi][r];
