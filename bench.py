@@ -349,10 +349,15 @@ def main():
         "profiled_ms_per_step": 1e3 * prof_elapsed / args.steps,
         "upload_and_prep_s": upload_s,
     }
-    print(json.dumps(out))
-    h.close()
+    h.close()   # (communicator and process group go first: anything RCCL still prints must not follow the JSON line)
     if dist is not None:
         dist.destroy_process_group()
+    try:  # RCCL prints its version banner through C stdio: when stdout is a pipe it would otherwise land AFTER the line below, at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

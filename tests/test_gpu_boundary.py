@@ -350,9 +350,14 @@ def test_bench_multi_gpu_branch_runs_with_a_forced_one_rank_communicator(tmp_pat
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-iters", "0", "--repeats", "1",
             "--size", "3000,2000,20"]
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NNLM_BENCH_FORCE_COMM="1")
-    sharded = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    def line_of(environment):
+        out = subprocess.run(base, env=environment, capture_output=True, text=True, check=True).stdout.strip().splitlines()
+        assert out and out[-1].startswith("{"), out[-3:]  # the JSON line is the LAST line of stdout (RCCL's banner is flushed before it)
+        return json.loads(out[-1])
+
+    sharded = line_of(env)
     env.pop("NNLM_BENCH_FORCE_COMM")
-    plain = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    plain = line_of(env)
     for line in (sharded, plain):
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                     "config", "roofline", "cpu_baseline"):
