@@ -72,14 +72,16 @@ def run_steps(h, cfg, steps, trace):
     return r
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm_summary.txt,
+def pmc_traffic(kernel, config=2):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this configuration
+    (profiles/rNN_<tag>_cfg<config>_pmc_hbm_summary.txt; round-1 files carry no cfg part and are configuration 2;
     separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command; KiB per dispatch).  gfx950 correction
     (MI355X_MICROARCH.md, HBM section): a wide streaming read is tallied at half its bytes, so reads = 2 x FETCH_SIZE.
     bench.py cannot attach rocprofv3 to itself: (None, None) when no summary holding the kernel is committed."""
     import glob, re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.txt")),
-                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v10 after r01_v9
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.txt"))
+             if f"_cfg{config}_" in os.path.basename(f) or ("_cfg" not in os.path.basename(f) and config == 2)]
+    files.sort(key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v10 after r01_v9, r02 after r01
     for path in reversed(files):
         fetch = write = None
         for line in open(path):
@@ -275,7 +277,7 @@ def main():
         c = classes[nm]
         ms_l = kern[nm]["ms_per_launch"]
         ach = c["work"] / (ms_l * 1e-3) / c["scale"]
-        traffic, src = (pmc_traffic(c["pmc"]) if (c["pmc"] and world == 1) else (None, None))
+        traffic, src = (pmc_traffic(c["pmc"], args.config) if (c["pmc"] and world == 1) else (None, None))
         b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
                  traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
         if "note" in c:

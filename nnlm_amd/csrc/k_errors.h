@@ -84,45 +84,42 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
 
 // ------------------------------------------------------------------------------------------------
 // F32 fast path of the error block.  128 x 128 tile of W H per 256-thread block:
-//   * the k x 128 slices of the fp32 [kq][col] copies of W and H go to LDS with global_load_lds ([kq][128]);
+//   * the k x 128 slices of the fp32 [kq][col] copies of W and H go to LDS with global_load_lds ([kq][128]), issued FIRST;
+//     the wavefront's 64 x 64 block of A (64 dword loads per lane) follows and stays in flight during the MFMA phase:
+//     vmcnt retires in order, so waiting until only the A loads are outstanding is waiting for the operands;
 //   * each wavefront forms a 64 x 64 block as 2 x 2 v_mfma_f32_32x32x2_f32 tiles with M = j and N = i, so that in the
 //     accumulator layout (column = lane & 31) the 32 lanes of a half-wave hold 32 CONSECUTIVE rows i of one column j:
 //     the matching A entries are read as full 128-byte lines (the generic kernel above reads 64-byte pieces);
+//   * missing entries (HAS_MISS) come from the TRANSPOSED bit matrix missT[i][j/32]: the 32 columns j of an accumulator
+//     tile are the 32 bits of ONE word of the lane's row i -- four word loads per lane instead of one per entry; the
+//     bounds of an edge tile are folded into the same words, so the sums have one masked and one unmasked form;
+//   * blocks are numbered so that an XCD (block id mod 8) always works on the same eighth of the i-tiles: its L2 keeps
+//     those W slices (0.5 MB) and the H slice of the current j-tile -- the W/H slices were 0.35 GB of L2 misses per
+//     launch against 0.8 GB of A (r01 PMC: 1.44x the algorithmic bytes);
 //   * per tile the two sums are accumulated in fp32 over the lane's 16 entries, then folded into fp64.
-// partial: [gridDim.y*gridDim.x][2] as above.
+// partial: [jtiles * nx][2] as above.  Grid: 1-D, 8 * ceil(nx / 8) * jtiles blocks.
 // ------------------------------------------------------------------------------------------------
 #define ERRF_TILE 128
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict__ A, int lda, const uint32_t *__restrict__ miss,
+template <bool HAS_MISS>
+__global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict__ A, int lda, const uint32_t *__restrict__ missT, int wordsT,
                                                          const float *__restrict__ Wf, int ldw,
                                                          const float *__restrict__ Hf, int ldh, int n, int m, int k2,
-                                                         double *__restrict__ partial, int jt0)
+                                                         double *__restrict__ partial, int jt0, int nx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_err[];
     float *Ws = (float *)smem_err;               // [k2][128]
     float *Hs = Ws + (size_t)k2 * ERRF_TILE;      // [k2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * ERRF_TILE, j0 = (blockIdx.y + jt0) * ERRF_TILE; // jt0: this rank's first j-tile
+    const int per = (nx + 7) >> 3;                // i-tiles per XCD
+    const int bid = blockIdx.x, it = ((bid >> 3) % per) * 8 + (bid & 7), jt = (bid >> 3) / per;
+    if (it >= nx) return;
+    const int i0 = it * ERRF_TILE, j0 = (jt + jt0) * ERRF_TILE; // jt0: this rank's first j-tile
     const int l31 = lane & 31, lh = lane >> 5;
     const int ib = 64 * (wave & 1), jb = 64 * (wave >> 1);
 
-    // 1. issue the HBM reads of this wavefront's 64 x 64 block of A first: their latency hides under the operand
-    //    staging and the MFMA phase.  D layout 32x32: row M = (r&3) + 8*(r>>2) + 4*(lane>>5), column N = lane & 31.
-    float av[2][2][16];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int i = i0 + ib + 32 * b + l31;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                av[a][b][r] = A[(size_t)j * lda + i];
-            }
-        }
-
-    // 2. k x 128 slices of W and H (fp32 [kq][col] copies) straight into LDS with global_load_lds: one instruction
+    // 1. k x 128 slices of W and H (fp32 [kq][col] copies) straight into LDS with global_load_lds: one instruction
     //    moves two 512-byte rows; all of them are in flight at once and use no VGPRs
     {
         const int nrow2 = k2 / 2; // instructions per matrix
@@ -134,8 +131,41 @@ __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict
             glds16(src, (unsigned char *)(isw ? Ws : Hs) + (size_t)tt * 1024);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("" ::: "memory");
+
+    // 2. the HBM reads of this wavefront's 64 x 64 block of A: the first half before the barrier, the second behind it; both
+    //    stay in flight during the MFMA phase.  D layout 32x32: row M = (r&3) + 8*(r>>2) + 4*(lane>>5), column N = lane & 31.
+    float av[2][2][16];
+    uint32_t mw[2][2];
+    const bool edge = (i0 + ERRF_TILE > n) || (j0 + ERRF_TILE > m);
+    const bool masked = HAS_MISS || edge; // (block uniform)
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int i = i0 + ib + 32 * b + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                av[a][b][r] = A[(size_t)j * lda + i];
+            }
+            uint32_t wd = 0;
+            if (HAS_MISS) wd = missT[(size_t)i * wordsT + ((j0 + jb + 32 * a) >> 5)];
+            if (edge) {
+                const int jbase = j0 + jb + 32 * a;
+                if (i >= n || jbase >= m) wd = ~0u;
+                else if (jbase + 32 > m) wd |= ~0u << (m - jbase);
+            }
+            mw[a][b] = wd >> (4 * lh); // bit of entry r: (r&3) + 8*(r>>2)
+        }
+        if (a == 0) {
+            // everything issued so far except the 32 loads of A (+ 2 mask words) has landed: the LDS image is complete
+            if (HAS_MISS) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
 
     // 3. W H for the block: 2 x 2 tiles of 32 x 32, contraction k
     f32x16 acc[2][2]; // [tj][ti]
@@ -159,37 +189,46 @@ __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict
     }
 
     // 4. the two sums
-    const bool interior = (i0 + ERRF_TILE <= n) && (j0 + ERRF_TILE <= m) && (miss == nullptr);
-    const int words = lda >> 5;
     double s2 = 0.0, skl = 0.0;
+    if (!masked) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int i = i0 + ib + 32 * b + l31;
-            float p2 = 0.f, pk = 0.f;
+            for (int b = 0; b < 2; b++) {
+                float p2 = 0.f, pk = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int j = j0 + jb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float ah = acc[a][b][r], aa = av[a][b][r];
-                const float d = aa - ah;
-                const float lg = __logf(ah + (float)NNLM_TINY);
-                float t2 = d * d;
-                float tk = __builtin_fmaf(-(aa + (float)NNLM_TINY), lg, ah);
-                if (!interior) {
-                    bool valid = (i < n) && (j < m);
-                    if (miss && valid) valid = !((miss[(size_t)j * words + (i >> 5)] >> (i & 31)) & 1u);
-                    if (!valid) {
-                        t2 = 0.f;
-                        tk = 0.f;
-                    }
+                for (int r = 0; r < 16; r++) {
+                    const float ah = acc[a][b][r], aa = av[a][b][r];
+                    const float d = aa - ah;
+                    const float l2 = log2_native(ah + (float)NNLM_TINY);
+                    const float cf = __builtin_fmaf(aa, -NNLM_LN2F, -(float)NNLM_TINY * NNLM_LN2F); // -(a + eps) ln 2
+                    p2 = __builtin_fmaf(d, d, p2);
+                    pk += __builtin_fmaf(cf, l2, ah);
                 }
-                p2 += t2;
-                pk += tk;
+                s2 += (double)p2;
+                skl += (double)pk;
             }
-            s2 += (double)p2;
-            skl += (double)pk;
-        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                float p2 = 0.f, pk = 0.f;
+                const uint32_t wd = mw[a][b];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float ah = acc[a][b][r], aa = av[a][b][r];
+                    const float d = aa - ah;
+                    const float l2 = log2_native(ah + (float)NNLM_TINY);
+                    const float cf = __builtin_fmaf(aa, -NNLM_LN2F, -(float)NNLM_TINY * NNLM_LN2F);
+                    const bool off = (wd >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                    p2 += off ? 0.f : d * d;
+                    pk += off ? 0.f : __builtin_fmaf(cf, l2, ah);
+                }
+                s2 += (double)p2;
+                skl += (double)pk;
+            }
+    }
     __shared__ double red[2][4];
     s2 = wave_sum(s2);
     skl = wave_sum(skl);
@@ -199,7 +238,7 @@ __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t blk = (size_t)jt * nx + it;
         partial[2 * blk] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
         partial[2 * blk + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
     }

@@ -388,9 +388,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                 const f32x4 d = aa - ah2;
                 f32x4 lg4;
 #pragma unroll
-                for (int r = 0; r < 4; r++) lg4[r] = __logf(ah2[r] + tiny);
+                for (int r = 0; r < 4; r++) lg4[r] = log2_native(ah2[r] + tiny); // (log2: ln 2 goes into the coefficient)
                 f32x4 t2 = d * d;
-                f32x4 tk = ah2 - (aa + tiny) * lg4;
+                f32x4 tk = ah2 - (aa * NNLM_LN2F + tiny * NNLM_LN2F) * lg4;
                 if (!interior) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {

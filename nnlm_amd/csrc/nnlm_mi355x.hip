@@ -1974,14 +1974,22 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
             nb = (size_t)grid.x * grid.y;
             errors_kernel<float><<<grid, 256, 0, st>>>((const float *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n, h->m, k4, h->partials, jt0);
         } else {
-            dim3 grid(h->npad / ERRF_TILE, jcnt);
-            nb = (size_t)grid.x * grid.y;
+            const int nx = h->npad / ERRF_TILE;
+            const unsigned grid = 8u * ((nx + 7) / 8) * jcnt; // (XCD-aware numbering: k_errors.h)
+            nb = (size_t)nx * jcnt;
             const int k2 = round_up_i(h->k, 2);
             const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
-            hipFuncSetAttribute((const void *)errors_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             const size_t cnt = (size_t)h->KP * h->mpad;
             factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(h->H64, cnt, h->Hkq);
-            errors_f32_kernel<<<grid, 256, lds, st>>>((const float *)h->A, h->npad, miss, (const float *)h->Wop, h->npad, h->Hkq, h->mpad, h->n, h->m, k2, h->partials, jt0);
+            if (h->any_missing) {
+                hipFuncSetAttribute((const void *)errors_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                errors_f32_kernel<true><<<grid, 256, lds, st>>>((const float *)h->A, h->npad, h->missT, h->mpad / 32, (const float *)h->Wop, h->npad, h->Hkq,
+                                                                h->mpad, h->n, h->m, k2, h->partials, jt0, nx);
+            } else {
+                hipFuncSetAttribute((const void *)errors_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                errors_f32_kernel<false><<<grid, 256, lds, st>>>((const float *)h->A, h->npad, nullptr, 0, (const float *)h->Wop, h->npad, h->Hkq, h->mpad,
+                                                                 h->n, h->m, k2, h->partials, jt0, nx);
+            }
         }
         reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, nb, 2, h->scal);
         if (h->sharded && h->comm) {
