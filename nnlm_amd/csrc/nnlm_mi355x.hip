@@ -1268,7 +1268,7 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
     if (total >= 0x7FFFFFFFull) return fail(h, NNLM_ERR_UNSUPPORTED, "missing-value row lists exceed 2^31 entries");
     HIPCHK(h, hipMalloc(&h->na_ptr[which], (size_t)(ncols + 1) * 4));
     HIPCHK(h, hipMalloc(&h->na_meta[which], (size_t)ncols * 4));
-    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 4) * 4));
+    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 16) * 4)); // (+16: na_gram_tail_kernel loads whole groups of four indices ahead)
     HIPCHK(h, hipMemcpyAsync(h->na_ptr[which], hptr.data(), (size_t)(ncols + 1) * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->na_meta[which], hmeta.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, h->stream));
     na_fill_kernel<<<ncols, 256, 0, h->stream>>>(bits, words, p, h->na_ptr[which], h->na_meta[which], h->na_idx[which]);
@@ -1300,6 +1300,18 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
         if (rc != NNLM_OK) return rc;
         const int nb = (nc + 3) / 4;
         // F32 mode: fp32 copy of the factor rows + v_mfma_f32_16x16x4_f32 (NNLM_NA_GRAM=f64 keeps the fp64 matrix cores for A/B runs)
+        static int tail_env = getenv("NNLM_NA_GRAM_TAIL") ? atoi(getenv("NNLM_NA_GRAM_TAIL")) : 1;
+        const int ntail = h->k - 16 * (h->NKQ - 1);
+        if (f32rows && tail_env && h->NKQ >= 2 && (ntail == 1 || ntail == 2)) { // k = 16 j + 1 or + 2: the tail coordinates on the VALU
+#define NNLM_NAGT(N_) na_gram_tail_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const float *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
+            switch (h->NKQ) {
+            case 2: NNLM_NAGT(1); break;
+            case 3: NNLM_NAGT(2); break;
+            default: NNLM_NAGT(3); break;
+            }
+#undef NNLM_NAGT
+            return NNLM_OK;
+        }
         if (f32rows) {
 #define NNLM_NAG(T_, N_) na_gram_mfma_kernel<T_, N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const T_ *)h->Yrow, h->Graw, h->Gcols, c1, c0)
             switch (h->NKQ) {
