@@ -401,140 +401,165 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
             }
 }
 
-// Tail form of the fp32 per-column Gram: k = 16 NT + 1 or 16 NT + 2 (the benchmark's k = 50 = 48 + 2).  The padded form above
-// spends 4 of its 10 tile products (NKQ = 4) on the tile that holds the two coordinates beyond 48 -- and its MFMA pipe is busy
-// 46 % of the kernel (PMC, profiles/r02_v8_cfg5_pmc_summary.txt).  Here the matrix cores get the NT full tiles only
-// (NT (NT + 1) / 2 products per four rows: 6 instead of 10) and the two tail coordinates are plain FMAs on the lanes that already
-// hold the row: ta[t] += y[c0] y[q], tb[t] += y[c1] y[q] for the lane's NT coordinates q, + the 2 x 2 corner -- 2 NT + 3 fp32
-// FMAs per four rows, issued under the MFMAs.  A lane sums ITS row of each group of four; the four lane groups are added at the
-// end.  Fewer accumulators (6 instead of 10 tiles in fp32 and fp64) also take the kernel from 3 to 4 wavefronts per SIMD.
-// Tile t, position l15 <-> coordinate NT l15 + t (one 4 NT-byte load per lane); entries beyond k are never read by the solvers and
-// are not written.
-template <int NT>
-__global__ __launch_bounds__(256) void na_gram_tail_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
-                                                           const float *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
-                                                           int ncols, int col0, int k)
+// fp32 per-column Gram with the listed rows gathered by LDS-DMA (global_load_lds_dwordx4): a group of four rows is ONE
+// instruction per wavefront (lane = 16-byte chunk: row lane / (KP/4), chunk lane % (KP/4)) that lands in one of four stage buffers
+// of the wavefront and occupies no VGPR.  Three groups are in flight while one is multiplied (s_waitcnt vmcnt(3), written by hand:
+// the instruction is issued as inline asm, so the compiler's wait-count pass neither sees it nor serialises the LDS reads behind
+// it).  Register-destination gathers (na_gram_mfma_kernel) leave the depth of the pipeline to the register
+// allocator: a rotated copy or a branch around a gather ends in "wait for everything".  The four row indices of a group are
+// scalar loads (lgkmcnt), two groups ahead.  Operands come from LDS in the natural layout (tile t, position l15 = coordinate
+// 16 t + l15).
+// TAIL: k = 16 NT + 1 or 16 NT + 2 (the benchmark's k = 50 = 48 + 2).  The padded form spends 4 of its 10 tile products (NKQ = 4) on
+// the tile that holds the two coordinates beyond 48, and its MFMA pipe was busy 46 % of the kernel (PMC,
+// profiles/r02_v8_cfg5_pmc_summary.txt).  Here the matrix cores get the NT full tiles only (6 instead of 10 products per four
+// rows) and the two tail coordinates are plain FMAs on the lanes that already hold the row: ta[t] += y[c0] y[q], tb[t] += y[c1] y[q]
+// for the lane's NT coordinates q, + the 2 x 2 corner -- 2 NT + 3 fp32 FMAs per four rows, issued under the MFMAs.  A lane sums
+// ITS row of each group of four; the four lane groups are added at the end.  The fp64 images of the tail sums are touched once
+// per 256 rows and live in LDS.  Entries beyond k are never read by the solvers and are not written.
+template <int NT, bool TAIL>
+__global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
+                                                          const float *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
+                                                          int ncols, int col0, int k)
 {
     using M = Mfma<float>;
-    constexpr int KP = 16 * (NT + 1);
+    constexpr int KP = 16 * (NT + (TAIL ? 1 : 0));
     constexpr int NP = NT * (NT + 1) / 2;
     constexpr int C0 = 16 * NT, C1 = 16 * NT + 1;
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
-    const int col = col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int CH = KP / 4;   // 16-byte chunks per row
+    constexpr int STG = 4;       // stage buffers per wavefront
+    constexpr int SF = 4 * KP;   // floats per stage: four rows
+    constexpr int NTL = TAIL ? 2 * NT + 3 : 1;
+    __shared__ __attribute__((aligned(16))) float stage_all[4][STG][SF];
+    __shared__ double tail64[4][NTL][64];
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
+    const int col = col0 + blockIdx.x * 4 + wave;
     if (col >= ncols) return; // whole wave
     const uint32_t mt = meta[col];
-    const int len = (int)(mt & 0x7FFFFFFFu);
+    const int ulen = __builtin_amdgcn_readfirstlane((int)(mt & 0x7FFFFFFFu));
     const bool complement = (mt >> 31) != 0;
-    const int *rows = idx + ptr[col];
+    const int base = __builtin_amdgcn_readfirstlane((int)ptr[col]);
+    float *stage = &stage_all[wave][0][0];
+    double(*t64)[64] = tail64[wave];
 
     f32x4 acc[NP];
     f64x4 acc64[NP];
     float ta[NT], tb[NT], tt[3] = {0.f, 0.f, 0.f};
-    // fp64 images of the tail sums: touched once per 256 rows, so they live in LDS (18 VGPRs less: 4 instead of 3 waves per SIMD)
-    __shared__ double tail64[4][2 * NT + 3][64];
-    double(*t64)[64] = tail64[threadIdx.x >> 6];
 #pragma unroll
     for (int i = 0; i < NP; i++) acc[i] = f32x4{0, 0, 0, 0}, acc64[i] = f64x4{0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NT; t++) ta[t] = tb[t] = 0.f;
+    if (TAIL) {
 #pragma unroll
-    for (int e = 0; e < 2 * NT + 3; e++) t64[e][lane] = 0.0;
+        for (int e = 0; e < NTL; e++) t64[e][lane] = 0.0;
+    }
 
+    struct Idx4 {
+        int a, b, c, d;
+    };
+    const int ngt = (ulen + 3) >> 2, ng = ulen >> 2; // groups, full groups
+    auto load_idx = [&](int g, Idx4 &ri) {            // (the list array carries 16 words of slack behind its end)
+        const int *src = idx + base + 4 * g;
+        ri.a = src[0], ri.b = src[1], ri.c = src[2], ri.d = src[3];
+    };
+    // DMA role of the lane
+    const int drow = lane / CH, dch = lane % CH;
+    const bool dact = lane < 4 * CH;
+    const int m1 = (drow == 1) ? -1 : 0, m2 = (drow == 2) ? -1 : 0, m3 = (drow == 3) ? -1 : 0;
+    const unsigned long long yp = (unsigned long long)Yrow;
+    const unsigned long long ybase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yp >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)yp);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float *)stage);
+    auto issue = [&](int g, const Idx4 &ri) { // group g (wave-uniform) into stage g % STG; rows past the end of the list repeat the group's first
+        int row = ri.a ^ ((ri.a ^ ri.b) & m1) ^ ((ri.a ^ ri.c) & m2) ^ ((ri.a ^ ri.d) & m3);
+        if (4 * g + drow >= ulen) row = ri.a;
+        const unsigned voff = (unsigned)row * (unsigned)(KP * 4) + (unsigned)dch * 16u;
+        const unsigned dst = lds0 + (unsigned)(g & (STG - 1)) * (unsigned)(SF * 4);
+        if (dact) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst) : "memory", "m0");
+    };
     struct Row {
         float x[NT];
         float tl[2];
     };
-    // The four row indices of a group are wave-uniform: SCALAR loads (lgkmcnt) one group ahead of the gathers that use them.  As
-    // vector loads they sat in the same in-order vmcnt queue as the gathers -- waiting for an index meant waiting for every gather
-    // issued before it, which cut the gather pipeline to one group in flight.
-    const int base = __builtin_amdgcn_readfirstlane((int)ptr[col]);
-    const int ulen = __builtin_amdgcn_readfirstlane(len);
-    struct Idx4 {
-        int a, b, c, d;
+    auto fetch = [&](int g, Row &r) { // operands of group g from its stage buffer
+        const float *sb = stage + (g & (STG - 1)) * SF + lg * KP;
+#pragma unroll
+        for (int t = 0; t < NT; t++) r.x[t] = sb[16 * t + l15];
+        if (TAIL) {
+            r.tl[0] = sb[C0];
+            r.tl[1] = sb[C1];
+        } else {
+            r.tl[0] = r.tl[1] = 0.f;
+        }
     };
-    auto load_idx = [&](int g, Idx4 &ri) { // (the list array carries 16 words of slack behind its end)
-        const int *src = idx + base + 4 * g;
-        ri.a = src[0], ri.b = src[1], ri.c = src[2], ri.d = src[3];
-    };
-    // lane group lg takes entry lg: four AND / OR with loop-invariant lane masks (a ?: chain becomes a scratch array here)
-    const int m0 = (lg == 0) ? -1 : 0, m1 = (lg == 1) ? -1 : 0, m2 = (lg == 2) ? -1 : 0, m3 = (lg == 3) ? -1 : 0;
-    // (full groups only: no lane predicate, so nothing has to merge with a pending gather; the last, partial group is separate)
-    auto load = [&](const Idx4 &ri, Row &dst) {
-        const int row = (ri.a & m0) | (ri.b & m1) | (ri.c & m2) | (ri.d & m3);
-        constexpr size_t AL = (NT == 3) ? 4 : 4 * NT;
-        const float *src = (const float *)__builtin_assume_aligned(Yrow + (size_t)row * KP + NT * l15, AL);
-        __builtin_memcpy(dst.x, src, 4 * NT);
-        const float *st = (const float *)__builtin_assume_aligned(Yrow + (size_t)row * KP + C0, 8);
-        __builtin_memcpy(dst.tl, st, 8);
-    };
-    // Three row buffers in fixed roles per unrolled step (no register rotation: a copy `xn = xnn` makes the compiler wait for the
-    // gather it has just issued): step g multiplies buffer g % 3 while the gathers of groups g + 1 and g + 2 are in flight.
-    Row b0, b1, b2;
-    Idx4 ri;
-    const int ng = ulen >> 2; // full groups of four rows
-    if (ng > 0) {
-        load_idx(0, ri);
-        load(ri, b0);
-        load_idx(ng > 1 ? 1 : 0, ri);
-        load(ri, b1);
-        load_idx(ng > 2 ? 2 : ng - 1, ri);
-    }
-    int since = 0;
     auto mult = [&](const Row &x) {
         int pi = 0;
 #pragma unroll
         for (int a = 0; a < NT; a++)
 #pragma unroll
             for (int b = a; b < NT; b++, pi++) acc[pi] = M::mma(x.x[a], x.x[b], acc[pi]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            ta[t] = __builtin_fmaf(x.tl[0], x.x[t], ta[t]);
-            tb[t] = __builtin_fmaf(x.tl[1], x.x[t], tb[t]);
-        }
-        tt[0] = __builtin_fmaf(x.tl[0], x.tl[0], tt[0]);
-        tt[1] = __builtin_fmaf(x.tl[0], x.tl[1], tt[1]);
-        tt[2] = __builtin_fmaf(x.tl[1], x.tl[1], tt[2]);
-    };
-    // The gathers of a step are UNCONDITIONAL (past the end the last group is fetched again and never used): with a branch around
-    // them the wait-count pass must assume the path without them, on which the buffer being multiplied is the newest request, and
-    // waits for everything (vmcnt(0)) -- the pipeline then holds no gather at all while the MFMAs run.
-    auto step = [&](int g, const Row &x, Row &dst) {
-        load(ri, dst);                                     // group min(g + 2, ng - 1)
-        load_idx((g + 3 < ng) ? g + 3 : ng - 1, ri);
-        mult(x);
-        if (++since == 64) { // 256 rows
-            since = 0;
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc64[i][r] += (double)acc[i][r];
-                acc[i] = f32x4{0, 0, 0, 0};
-            }
+        if (TAIL) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                t64[t][lane] += (double)ta[t], t64[NT + t][lane] += (double)tb[t];
-                ta[t] = tb[t] = 0.f;
+                ta[t] = __builtin_fmaf(x.tl[0], x.x[t], ta[t]);
+                tb[t] = __builtin_fmaf(x.tl[1], x.x[t], tb[t]);
             }
-#pragma unroll
-            for (int e = 0; e < 3; e++) t64[2 * NT + e][lane] += (double)tt[e], tt[e] = 0.f;
+            tt[0] = __builtin_fmaf(x.tl[0], x.tl[0], tt[0]);
+            tt[1] = __builtin_fmaf(x.tl[0], x.tl[1], tt[1]);
+            tt[2] = __builtin_fmaf(x.tl[1], x.tl[1], tt[2]);
         }
     };
-    int g = 0;
-    for (; g + 3 <= ng; g += 3) {
-        step(g, b0, b2);
-        step(g + 1, b1, b0);
-        step(g + 2, b2, b1);
-    }
-    if (g < ng) step(g, b0, b2);
-    if (g + 1 < ng) step(g + 1, b1, b0);
-    if (ulen & 3) { // the last one to three rows: lane groups beyond the end multiply zeros
-        load_idx(ng, ri);
-        Row last;
+    if (ngt > 0) {
+        // prologue: groups 0, 1, 2 (clamped) in flight, indices of group 3 requested
+        Idx4 ri;
+        const int last = ngt - 1;
+        load_idx(0, ri);
+        issue(0, ri);
+        load_idx(last < 1 ? last : 1, ri);
+        issue(last < 1 ? last : 1, ri); // (a clamped group lands in the stage of its own number: never the one being read, see below)
+        load_idx(last < 2 ? last : 2, ri);
+        issue(last < 2 ? last : 2, ri);
+        load_idx(last < 3 ? last : 3, ri);
+        int since = 0;
+        for (int g = 0; g < ng; g++) {
+            // group g + 3 goes into the stage group g - 1 was read from (its operands were in registers before its MFMAs issued).
+            // Past the end the LAST group is fetched again, into its own stage and with its own data: harmless whenever it lands.
+            const int gi = (g + 3 < last) ? g + 3 : last;
+            issue(gi, ri);
+            load_idx((g + 4 < last) ? g + 4 : last, ri);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // groups g + 1 .. g + 3 may still be on their way
+            Row x;
+            fetch(g, x);
+            mult(x);
+            if (++since == 64) { // 256 rows: fp32 partial sums into their fp64 images
+                since = 0;
 #pragma unroll
-        for (int t = 0; t < NT; t++) last.x[t] = 0.f;
-        last.tl[0] = last.tl[1] = 0.f;
-        if (4 * ng + lg < ulen) load(ri, last);
-        mult(last);
+                for (int i = 0; i < NP; i++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc64[i][r] += (double)acc[i][r];
+                    acc[i] = f32x4{0, 0, 0, 0};
+                }
+                if (TAIL) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        t64[t][lane] += (double)ta[t], t64[NT + t][lane] += (double)tb[t];
+                        ta[t] = tb[t] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 3; e++) t64[2 * NT + e][lane] += (double)tt[e], tt[e] = 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (nothing may land in LDS after the wavefront has gone)
+        if (ulen & 3) {                                   // the last one to three rows: lane groups beyond the end multiply zeros
+            Row x;
+            fetch(ng, x);
+            if (4 * ng + lg >= ulen) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) x.x[t] = 0.f;
+                x.tl[0] = x.tl[1] = 0.f;
+            }
+            mult(x);
+        }
     }
     double *out = Gcols + (size_t)col * KP * KP;
     auto put = [&](int i, int j, double sum) { // both triangles
@@ -542,7 +567,6 @@ __global__ __launch_bounds__(256) void na_gram_tail_kernel(const uint32_t *__res
         out[i * KP + j] = v;
         if (i != j) out[j * KP + i] = v;
     };
-    // full tiles.  C/D layout: reg r -> tile row M::row_of(lane, r), tile column l15, i.e. coordinates (NT row + a, NT l15 + b)
     int pi = 0;
 #pragma unroll
     for (int a = 0; a < NT; a++)
@@ -550,37 +574,41 @@ __global__ __launch_bounds__(256) void na_gram_tail_kernel(const uint32_t *__res
         for (int b = a; b < NT; b++, pi++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = NT * M::row_of(lane, r) + a, j = NT * l15 + b;
+                const int i = 16 * a + M::row_of(lane, r), j = 16 * b + l15;
                 const double sum = acc64[pi][r] + (double)acc[pi][r];
                 const double v = complement ? Gfull[i * KP + j] - sum : sum;
-                out[i * KP + j] = v;
-                if (a != b) out[j * KP + i] = v;
+                if (TAIL || (i < k && j < k)) { // (entries beyond k are never read by the solvers)
+                    out[i * KP + j] = v;
+                    if (a != b) out[j * KP + i] = v;
+                }
             }
-    // tail rows: add the four lane groups (each summed its own row of every group of four), then lane group 0 stores row C0,
-    // lane group 1 row C1, lane 32 the corner
+    if (TAIL) {
+        // tail rows: add the four lane groups (each summed its own row of every group of four); lane group 0 stores row C0, lane
+        // group 1 row C1, lane 32 the corner
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        double va = t64[t][lane] + (double)ta[t], vb = t64[NT + t][lane] + (double)tb[t];
-        va += __shfl_xor(va, 16, 64);
-        va += __shfl_xor(va, 32, 64);
-        vb += __shfl_xor(vb, 16, 64);
-        vb += __shfl_xor(vb, 32, 64);
-        const int q = NT * l15 + t;
-        if (lg == 0) put(C0, q, va);
-        if (lg == 1 && C1 < k) put(C1, q, vb);
-    }
-    double c[3];
+        for (int t = 0; t < NT; t++) {
+            double va = t64[t][lane] + (double)ta[t], vb = t64[NT + t][lane] + (double)tb[t];
+            va += __shfl_xor(va, 16, 64);
+            va += __shfl_xor(va, 32, 64);
+            vb += __shfl_xor(vb, 16, 64);
+            vb += __shfl_xor(vb, 32, 64);
+            const int q = 16 * t + l15;
+            if (lg == 0) put(C0, q, va);
+            if (lg == 1 && C1 < k) put(C1, q, vb);
+        }
+        double c[3];
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
-        c[e] = t64[2 * NT + e][lane] + (double)tt[e];
-        c[e] += __shfl_xor(c[e], 16, 64);
-        c[e] += __shfl_xor(c[e], 32, 64);
-    }
-    if (lane == 32) {
-        put(C0, C0, c[0]);
-        if (C1 < k) {
-            put(C0, C1, c[1]);
-            put(C1, C1, c[2]);
+        for (int e = 0; e < 3; e++) {
+            c[e] = t64[2 * NT + e][lane] + (double)tt[e];
+            c[e] += __shfl_xor(c[e], 16, 64);
+            c[e] += __shfl_xor(c[e], 32, 64);
+        }
+        if (lane == 32) {
+            put(C0, C0, c[0]);
+            if (C1 < k) {
+                put(C0, C1, c[1]);
+                put(C1, C1, c[2]);
+            }
         }
     }
 }

@@ -1268,7 +1268,7 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
     if (total >= 0x7FFFFFFFull) return fail(h, NNLM_ERR_UNSUPPORTED, "missing-value row lists exceed 2^31 entries");
     HIPCHK(h, hipMalloc(&h->na_ptr[which], (size_t)(ncols + 1) * 4));
     HIPCHK(h, hipMalloc(&h->na_meta[which], (size_t)ncols * 4));
-    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 16) * 4)); // (+16: na_gram_tail_kernel loads whole groups of four indices ahead)
+    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 16) * 4)); // (+16: na_gram_lds_kernel loads whole groups of four indices ahead)
     HIPCHK(h, hipMemcpyAsync(h->na_ptr[which], hptr.data(), (size_t)(ncols + 1) * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->na_meta[which], hmeta.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, h->stream));
     na_fill_kernel<<<ncols, 256, 0, h->stream>>>(bits, words, p, h->na_ptr[which], h->na_meta[which], h->na_idx[which]);
@@ -1301,15 +1301,18 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
         const int nb = (nc + 3) / 4;
         // F32 mode: fp32 copy of the factor rows + v_mfma_f32_16x16x4_f32 (NNLM_NA_GRAM=f64 keeps the fp64 matrix cores for A/B runs)
         static int tail_env = getenv("NNLM_NA_GRAM_TAIL") ? atoi(getenv("NNLM_NA_GRAM_TAIL")) : 1;
+        static int lds_env = getenv("NNLM_NA_GRAM_LDS") ? atoi(getenv("NNLM_NA_GRAM_LDS")) : 1;
         const int ntail = h->k - 16 * (h->NKQ - 1);
-        if (f32rows && tail_env && h->NKQ >= 2 && (ntail == 1 || ntail == 2)) { // k = 16 j + 1 or + 2: the tail coordinates on the VALU
-#define NNLM_NAGT(N_) na_gram_tail_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const float *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
+        if (f32rows && lds_env) { // rows gathered by LDS-DMA (k_missing.h, na_gram_lds_kernel); NNLM_NA_GRAM_LDS=0: register gathers
+            const bool tl = tail_env && h->NKQ >= 2 && (ntail == 1 || ntail == 2);
+#define NNLM_NAGL(N_, T_) na_gram_lds_kernel<N_, T_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const float *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
             switch (h->NKQ) {
-            case 2: NNLM_NAGT(1); break;
-            case 3: NNLM_NAGT(2); break;
-            default: NNLM_NAGT(3); break;
+            case 1: NNLM_NAGL(1, false); break;
+            case 2: if (tl) NNLM_NAGL(1, true); else NNLM_NAGL(2, false); break;
+            case 3: if (tl) NNLM_NAGL(2, true); else NNLM_NAGL(3, false); break;
+            default: if (tl) NNLM_NAGL(3, true); else NNLM_NAGL(4, false); break;
             }
-#undef NNLM_NAGT
+#undef NNLM_NAGL
             return NNLM_OK;
         }
         if (f32rows) {

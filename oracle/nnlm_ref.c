@@ -280,7 +280,7 @@ int ref_update_with_missing(double *H, const double *Wt, const double *A, const 
         double *sumW = (double *)malloc(sizeof(double) * (size_t)k);
         double *Wsub = (double *)malloc(sizeof(double) * (size_t)k * n); /* Wt.cols(non_missing) */
         double *Asub = (double *)malloc(sizeof(double) * (size_t)n);     /* A.elem(j*n + non_missing) */
-        double *scratch = (double *)malloc(sizeof(double) * (size_t)n);
+        double *scratch = (double *)malloc(sizeof(double) * (size_t)(n > k ? n : k)); /* (holds k gradients below: k may exceed n) */
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic)
 #endif

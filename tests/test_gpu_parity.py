@@ -602,6 +602,44 @@ def test_kl_contraction_longer_than_32768(pname, prec, tol, method):
         assert relF(W1, Wt_ref.T) < 10 * tol
 
 
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+@pytest.mark.parametrize("k", [16, 17, 18, 32, 33, 40, 49, 50, 64])
+def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
+    """update_with_missing (src/update_with_missing.cpp:58-139) over the forms of the per-column Gram kernel (k_missing.h,
+    na_gram_lds_kernel): whole tiles (16, 32, 64), tail coordinates on the VALU (17, 18, 33, 49, 50), a padded last tile (40);
+    columns with no missing entry (empty row list), with one, with 2-3 rows beyond a multiple of four, with more than half missing
+    (the list then holds the PRESENT rows), and an all-missing column."""
+    rng = np.random.default_rng(1000 + k)
+    n, m = 203, 37
+    A = rng.random((n, m)) + 0.1
+    A[rng.random((n, m)) < 0.1] = np.nan
+    A[:, 0] = rng.random(n) + 0.1          # no missing entry
+    A[:, 1] = rng.random(n) + 0.1
+    A[5, 1] = np.nan                        # exactly one
+    A[:, 2] = rng.random(n) + 0.1
+    A[[3, 9, 100, 150, 151, 152, 200], 2] = np.nan  # 7 = 4 + 3
+    A[rng.random(n) < 0.7, 3] = np.nan     # mostly missing
+    A[:, 4] = np.nan                        # nothing observed
+    A[7, :] = np.nan                        # a row of the W half-step with nothing observed
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    reg = [0.02, 0.01, 0.03]
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(k, W0, H0)
+        h.half_step(1, reg, 4, 1e-9, 1)
+        _, H1 = h.get_factors()
+        s1 = h.take_sweeps()
+        H_ref, it1 = ref.update(H0, W0.T.copy(), A, None, reg, 4, 1e-9, 1)
+        assert relF(H1, H_ref) < tol
+        h.half_step(0, reg, 4, 1e-9, 1)
+        W1, _ = h.get_factors()
+        s2 = h.take_sweeps()
+        Wt_ref, it2 = ref.update(W0.T.copy(), H_ref, A.T.copy(), None, reg, 4, 1e-9, 1)
+        assert relF(W1, Wt_ref.T) < 10 * tol
+        if pname == "f64":
+            assert (s1, s2) == (it1, it2)
+
+
 # ---- column-sharded half-steps (missing values, KL methods): all-gather only -------------------------------------------
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3])
