@@ -9,7 +9,8 @@ A "step" is one outer iteration of nnmf(): W half-step + H half-step (src/nnmf.c
 steps, the error block (src/nnmf.cpp:135-160).  Default workload = BASELINE.json configs[1]: nnmf(A, k=50), MSE loss,
 sequential coordinate descent, dense A 20000 x 10000 = U(0,1) synthetic, explicit 0.01*U(0,1) init, R defaults
 inner.max.iter=50, inner.rel.tol=1e-9, trace=2, rel.tol=-1 (fixed work).  A, W, H are resident in HBM when the timed
-region starts.  N > 1: A replicated, each rank contracts its slab, one RCCL all-reduce per half-step (strong scaling).
+region starts.  N > 1: A replicated, every rank does the half-step of its 1/N of the columns, one RCCL all-gather per half-step
+(strong scaling; NNLM_SHARD_DENSE=reduce: contraction-sharded + all-reduce + all-gather).
 `--config 3` / `--config 5` time BASELINE.json configs[2] (KL + Lee) / configs[4] (10 % NA + L1/L2) the same way (second
 bench lines for profiles/; the driver's line is the default config 2).  `--protocol core` = SURVEY section 8d's P-core (no
 error block inside the timed iterations).
@@ -256,7 +257,7 @@ def main():
                 # the sweeps are a loop-carried recurrence (SURVEY 8d grants them no HBM/MFMA roofline): priced as achieved fp64
                 # arithmetic of the recurrence, inner*cols*k*(2k+8) flops per launch, against the fp64 matrix/vector peak
                 fl = inner * (cols / world) * k * (2 * k + 8)
-                knm = "na_gram_mfma_kernel + colsolve" if cfg["na"] else "sweep_scd_wgf_kernel"
+                knm = "na_gram_lds_kernel + colsolve_fast_kernel" if cfg["na"] else "sweep_scd_wgf_kernel"
                 if cfg["na"]:
                     fl += 2.0 * k * k * (n * m // 10)  # per-column Grams over the complement rows (2 k^2 per missing entry)
                 classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=FP64_PEAK_TF, unit="TFLOP/s", scale=1e12, pmc=None,
@@ -336,7 +337,9 @@ def main():
                               if os.environ.get("NNLM_XPROD", "") != "f32" else
                               "A + cross-product GEMMs fp32 MFMA (fp64 flush every 256)") + "; Gram/mu/sweeps fp64; KL solvers fp32 state" if s == 4
                              else "all fp64 (v_mfma_f64_16x16x4_f64)"),
-                   "parallelism": (f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
+                   "parallelism": ((f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
+                                    if os.environ.get("NNLM_SHARD_DENSE", "") == "reduce" and method < 3 and not cfg["na"] else
+                                    f"columns sharded x{world} (cross product, Gram, sweep of a rank's columns) + 1 RCCL all-gather per half-step")
                                    if (world > 1 or force_comm) else "1 GPU")},
         "repeats": {"ms_per_step": ms_all, "min": min(ms_all), "median": float(np.median(ms_all)), "max": max(ms_all),
                     "final_mse": mses, "note": "consecutive timed regions of `steps` iterations each; `value` is the first"},

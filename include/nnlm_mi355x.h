@@ -150,13 +150,16 @@ int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_ms, long lo
 int nnlm_profile_reset(nnlm_handle *h);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated.  Per half-step each rank
- * contracts its slab of rows (H half-step) / columns (W half-step); ONE ncclAllReduce sums the
- * partial [Gram | cross-product] buffer; each rank then solves its own 1/N of the columns and ONE
- * ncclAllGather returns the updated factor to every rank.  With missing values (per-column Grams)
- * and for the KL methods the column is the unit: a rank does all the work of its columns over the
- * whole contraction and only the all-gather remains.  Error block: each rank reduces its share of
- * A, two doubles are all-reduced.
+ * Multi-GPU (one process per GPU, RCCL over xGMI).  A is replicated.  The column of the factor being
+ * solved is the unit: per half-step a rank forms the cross product of ITS 1/N of the columns over the
+ * whole contraction (1/N of A from HBM), the Gram of the fixed factor (dense: one shared k x k Gram,
+ * replicated; missing values: one per column), solves its columns into a packed slab, and ONE
+ * ncclAllGather returns the updated factor to every rank.  Dense square loss also has the form
+ * north_star words (environment NNLM_SHARD_DENSE=reduce, read by nnlm_comm_init): each rank contracts
+ * its slab of rows (H half-step) / columns (W half-step), ONE ncclAllReduce sums the partial
+ * [Gram | cross-product] buffer, then the column-sharded sweep and the all-gather -- same HBM bytes and
+ * kernel time per rank (profiles/r02_shard_times.json), one more collective of (KP^2 + KP cols) doubles.
+ * Error block: each rank reduces its share of A, two doubles are all-reduced.
  * ---------------------------------------------------------------------------------------- */
 #define NNLM_COMM_ID_BYTES 128
 int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */

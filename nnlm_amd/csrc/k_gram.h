@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restri
 }
 
 // Multi-GPU: scatter the all-gathered per-rank slabs of the updated factor back into the resident layouts.
-// packed [nranks][KP][cpr] (rank rr holds columns rr*cpr .. of the factor); X [KP][ldx] master; op = GEMM operand copy
+// packed [nranks][KP][cpr] with KP = the rows that travelled (the caller passes k: the padding rows of a slab are not gathered);
+// rank rr holds columns rr*cpr .. of the factor; X [KP][ldx] master; op = GEMM operand copy
 // (op_mode 1: [KP][op_ld] same layout as X, 2: [col][op_ld] kq fastest, 0: none), element type float or double.
 __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KP, int cpr, int k,
                                                            int ncols, double *__restrict__ X, int ldx, void *__restrict__ op,

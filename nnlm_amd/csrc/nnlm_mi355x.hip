@@ -60,6 +60,7 @@ struct nnlm_handle {
     uint32_t *miss = nullptr;   // [mpad][npad/32]
     uint32_t *missT = nullptr;  // [npad][mpad/32], only when any_missing
     bool any_missing = false;
+    bool dense_cols = true;     // multi-GPU form of the dense square-loss half-step (half_step): column-sharded (true) or all-reduce
     double n_non_missing = 0.0, kl_const = 0.0;
 
     // factors
@@ -1539,7 +1540,13 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // Missing values across GPUs: every column has a Gram of its own, so the column is the unit: a rank forms the
     // cross product of ITS columns over the whole contraction, their Grams, solves them, and ONE all-gather returns the factor --
     // no all-reduce.  Test hooks: phase 1 is empty, phase 2 computes and packs, phase 3 unpacks.
-    const bool colshard = h->sharded && h->any_missing;
+    // Dense square loss across GPUs, two forms.  "reduce" (north_star's wording): contraction-sharded [G | C], one
+    // all-reduce, column-sharded sweep, one all-gather.  "cols": the column-sharded form of the NA / KL paths -- a rank forms the cross
+    // product of ITS columns over the whole contraction (it holds all of A and, after the previous all-gather, all of the fixed
+    // factor), the full Gram of the fixed factor (2 k^2 p flops, replicated), sweeps its columns, ONE all-gather.  Same HBM bytes per
+    // rank (1/N of A either way), no all-reduce of the (KP^2 + KP cols) doubles: NNLM_SHARD_DENSE=reduce|cols (default cols).
+    // (read when the communicator is set up: nnlm_comm_init)
+    const bool colshard = h->sharded && (h->any_missing || h->dense_cols);
     if (colshard && phase == PH_A) return NNLM_OK;
     if (phase == PH_C || (phase == PH_B && !colshard)) {
         const HalfPlan pp = plan_half(h, which, h->rank, h->nranks);
@@ -1688,13 +1695,13 @@ static int shard_unpack(nnlm_handle *h, int which)
 {
     const int ncols = (which == 1) ? h->m : h->n;
     const ShardCols sc = shard_cols(h, ncols);
-    const size_t tot = (size_t)h->nranks * h->KP * sc.cpr;
+    const size_t tot = (size_t)h->nranks * h->k * sc.cpr; // (the k meaningful rows of every rank's [KP][cpr] slab travel, not the padding)
     const int f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
     if (which == 1)
-        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->KP, sc.cpr, h->k, ncols, h->H64,
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols, h->H64,
                                                                                    h->mpad, h->Hop, 2, h->KP, f64);
     else
-        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->KP, sc.cpr, h->k, ncols,
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols,
                                                                                    h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
                                                                                    f64 ? 0 : 1, h->npad, f64);
     HIPCHK(h, hipGetLastError());
@@ -1725,7 +1732,7 @@ static int pack_gather_unpack(nnlm_handle *h, int which, int phase)
     const int ncols = (which == 1) ? h->m : h->n;
     const ShardCols sc = shard_cols(h, ncols);
     if (h->comm) {
-        ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->KP * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream);
+        ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->k * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream); // rows 0 .. k-1
         if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     } else if (phase == PH_ALL)
         return fail(h, NNLM_ERR_COMM, "virtual rank %d of %d has no communicator: drive it with nnlm_debug_phase()", h->rank, h->nranks);
@@ -1906,7 +1913,7 @@ extern "C" int nnlm_debug_exchange(nnlm_handle **hs, int P, int which, int stage
     } else {
         const int ncols = (which == 1) ? h0->m : h0->n;
         const ShardCols sc = shard_cols(h0, ncols);
-        const size_t per = (size_t)h0->KP * sc.cpr;
+        const size_t per = (size_t)h0->k * sc.cpr; // (as the ncclAllGather call: the first k rows of the slab)
         std::vector<double> all(per * P);
         for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(all.data() + per * r, hs[r]->pack_send, per * 8, hipMemcpyDeviceToHost));
         for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(hs[r]->pack_all, all.data(), per * P * 8, hipMemcpyHostToDevice));
@@ -2121,6 +2128,10 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     h->rank = rank;
     h->nranks = nranks;
     h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
+    {
+        const char *form = getenv("NNLM_SHARD_DENSE"); // "reduce": contraction-sharded + all-reduce; default "cols": column-sharded, all-gather only
+        h->dense_cols = !(form && strcmp(form, "reduce") == 0);
+    }
     if (!id) return NNLM_OK;
     int rc = rccl_load();
     if (rc != NNLM_OK) return rc;

@@ -1,5 +1,6 @@
-"""Per-rank kernel times of the sharded dense half-step at config 2, measured on ONE GPU with virtual ranks (the collectives are
-not timed: a virtual rank has no communicator).  Feeds DESIGN.md section 6's scaling model."""
+"""Per-rank kernel times of the sharded dense half-step at config 2, both forms (column-sharded: phase "contract" is empty and "sweep" is
+cross product + Gram + sweep of the rank's columns; reduce: contraction slab, then sweep), measured on ONE GPU with virtual ranks (the
+collectives are not timed: a virtual rank has no communicator).  Feeds DESIGN.md section 6's scaling model."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +11,8 @@ rng = np.random.default_rng(20250928)
 A = rng.random((n, m)); W0 = 0.01 * rng.random((n, k)); H0 = 0.01 * rng.random((k, m))
 z = [0.0, 0.0, 0.0]
 out = {}
-for world in (1, 2, 4, 8):
+for form, world in [("cols", 1)] + [(f, w) for f in ("cols", "reduce") for w in (2, 4, 8)]:
+    os.environ["NNLM_SHARD_DENSE"] = form  # (read by nnlm_comm_init)
     with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
         if world > 1:
             h.comm_init(None, world - 1, world)  # the last rank (ragged shard)
@@ -31,6 +33,6 @@ for world in (1, 2, 4, 8):
                     h.sync(); t0 = time.perf_counter(); h.debug_phase(which, 3, z, 50, -1.0, 1); h.sync(); ts[3].append(time.perf_counter() - t0)
                 h.set_factors(k, W0, H0)
             res["W" if which == 0 else "H"] = {("half_step" if world == 1 else {1: "contract", 2: "sweep", 3: "unpack"}[ph]): round(1e3 * min(v), 4) for ph, v in ts.items() if v}
-        out[world] = res
-        print(world, json.dumps(res), flush=True)
+        out[f"{form}_{world}" if world > 1 else "1"] = res
+        print(form, world, json.dumps(res), flush=True)
 json.dump(out, open("gpurun_out/r02/shard_times.json", "w"))

@@ -1,14 +1,14 @@
 """Worker for tests/test_dist_cpu.py: one rank of the SHIPPED multi-GPU exchange on CPU (gloo), driven by the product's own
 partition functions exported through the C ABI (nnlm_shard_range, nnlm_shard_cols; no GPU needed for those).
 
-Dense square-loss half-step (nnlm_mi355x.hip half_step / half_step_solve):
+Dense square-loss half-step, form "reduce" (NNLM_SHARD_DENSE=reduce; nnlm_mi355x.hip half_step / half_step_solve):
     1. every rank contracts ITS slab of the contraction (nnlm_shard_range) into one buffer [G (k x k) | C (k x cols)];
     2. ONE all_reduce(sum) of that buffer                                       (ncclAllReduce);
     3. every rank solves ITS columns [col0, col1) (nnlm_shard_cols) into a packed slab [k][cpr], zero padded;
     4. ONE all_gather of the slabs                                              (ncclAllGather);
     5. unpack: column rr*cpr + lc of the factor = entry lc of rank rr's slab    (shard_unpack_kernel).
-Missing values / KL methods (column is the unit): a rank does all the work of its columns over the WHOLE contraction
-(step 1-2 disappear), then 3-5.
+Column-sharded form (missing values, KL methods, and the DEFAULT for dense square loss): a rank does all the work of its columns
+over the WHOLE contraction (step 1-2 disappear: no all-reduce), then 3-5.
 The per-column arithmetic is the oracle's (this tests the exchange and its index arithmetic, not the kernels); every rank
 must end with bit-identical factors."""
 import os
@@ -72,7 +72,7 @@ def dense_half_step(which, A, Wt, H, reg, inner, tol, method, rank, world, prec)
 
 
 def column_half_step(which, A, Wt, H, reg, inner, tol, method, rank, world):
-    """Missing values (methods 1, 2) and KL methods (3, 4): no all-reduce, the rank's columns over the whole contraction."""
+    """Column-sharded form (dense and missing values, methods 1-4): no all-reduce, the rank's columns over the whole contraction."""
     if which == 1:
         Yt, X, B = Wt, H, A
     else:
@@ -113,7 +113,8 @@ def main():
             res[f"cols_{prec}_{method}"] = np.array([c0, c1])
     Ana = A.copy()
     Ana.ravel()[np.random.default_rng(7).choice(A.size, A.size // 10, replace=False)] = np.nan
-    for tag, Amat, method, inner in (("na1", Ana, 1, 4), ("na2", Ana, 2, 4), ("kl3", A, 3, 2), ("kl4", A, 4, 2), ("nakl", Ana, 4, 1)):
+    for tag, Amat, method, inner in (("dense1", A, 1, 4), ("dense2", A, 2, 4), ("na1", Ana, 1, 4), ("na2", Ana, 2, 4), ("kl3", A, 3, 2), ("kl4", A, 4, 2),
+                                     ("nakl", Ana, 4, 1)):
         Wn, t0, _ = column_half_step(0, Amat, Wt, H, reg, inner, 1e-9, method, rank, world)
         Hn, t1, _ = column_half_step(1, Amat, Wn, H, reg, inner, 1e-9, method, rank, world)
         res[f"W_{tag}"], res[f"H_{tag}"], res[f"it_{tag}"] = Wn, Hn, np.array([t0, t1])

@@ -1,9 +1,9 @@
 """World-size-2 gloo test of the multi-GPU path's exchange on CPU (no GPU needed).
 
-GPU side (nnlm_amd/csrc/nnlm_mi355x.hip half_step / half_step_solve / half_step_kl): dense square-loss half-steps =
-contraction-sharded [Gram | cross-product] partials -> ONE ncclAllReduce -> column-sharded solve into packed [k][cpr] slabs ->
-ONE ncclAllGather -> unpack; missing values and KL methods = column-sharded work over the whole contraction -> all-gather ->
-unpack.  tests/dist_worker.py runs exactly that exchange with torch.distributed/gloo, taking every range from the product's own
+GPU side (nnlm_amd/csrc/nnlm_mi355x.hip half_step / half_step_solve / half_step_kl), two forms.  Column-sharded (default for
+everything: dense, missing values, KL): a rank does all the work of ITS columns over the whole contraction into a packed [k][cpr]
+slab -> ONE ncclAllGather -> unpack.  "reduce" (dense square loss with NNLM_SHARD_DENSE=reduce, north_star's wording):
+contraction-sharded [Gram | cross-product] partials -> ONE ncclAllReduce -> column-sharded solve -> ONE ncclAllGather -> unpack.  tests/dist_worker.py runs exactly that exchange with torch.distributed/gloo, taking every range from the product's own
 partition functions (nnlm_shard_range, nnlm_shard_cols through the C ABI); the results must equal the unsharded oracle."""
 import os
 import socket
@@ -78,10 +78,11 @@ def test_two_rank_sharded_half_steps_equal_unsharded_oracle(tmp_path):
             assert np.array_equal(z0[f"H_{prec}_{method}"], z1[f"H_{prec}_{method}"])
             assert not np.array_equal(z0[f"rng_{prec}_{method}"], z1[f"rng_{prec}_{method}"])
             assert not np.array_equal(z0[f"cols_{prec}_{method}"], z1[f"cols_{prec}_{method}"])
-    # column-sharded forms: missing values (per-column Grams) and the KL methods
+    # column-sharded form: dense square loss (the default), missing values (per-column Grams) and the KL methods
     Ana = A.copy()
     Ana.ravel()[np.random.default_rng(7).choice(A.size, A.size // 10, replace=False)] = np.nan
-    for tag, Amat, method, inner in (("na1", Ana, 1, 4), ("na2", Ana, 2, 4), ("kl3", A, 3, 2), ("kl4", A, 4, 2), ("nakl", Ana, 4, 1)):
+    for tag, Amat, method, inner in (("dense1", A, 1, 4), ("dense2", A, 2, 4), ("na1", Ana, 1, 4), ("na2", Ana, 2, 4), ("kl3", A, 3, 2),
+                                     ("kl4", A, 4, 2), ("nakl", Ana, 4, 1)):
         Wn_ref, it0 = ref.update(Wt, H, Amat.T.copy(), None, reg, inner, 1e-9, method)
         Hn_ref, it1 = ref.update(H, Wn_ref, Amat, None, reg, inner, 1e-9, method)
         for z in zs:

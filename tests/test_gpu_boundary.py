@@ -363,5 +363,5 @@ def test_bench_multi_gpu_branch_runs_with_a_forced_one_rank_communicator(tmp_pat
                     "config", "roofline", "cpu_baseline"):
             assert key in line, key
         assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "strong"
-    assert "all-reduce" in sharded["config"]["parallelism"] and plain["config"]["parallelism"] == "1 GPU"
+    assert "all-gather" in sharded["config"]["parallelism"] and plain["config"]["parallelism"] == "1 GPU"
     assert abs(sharded["final_mse"] - plain["final_mse"]) < 1e-6 * plain["final_mse"]

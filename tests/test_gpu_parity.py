@@ -341,9 +341,10 @@ def test_config2_full_size_one_iteration_vs_oracle_and_properties():
 # ---- multi-GPU shard arithmetic with virtual ranks on one device ---------------------------------------
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_virtual_rank_partials_sum_to_the_unsharded_buffer(pname, prec, tol, world):
-    """Each virtual rank computes only its slab's [Gram | cross-product]; their sum (what ncclAllReduce forms) equals
+def test_virtual_rank_partials_sum_to_the_unsharded_buffer(monkeypatch, pname, prec, tol, world):
+    """(The all-reduce form of the dense half-step, NNLM_SHARD_DENSE=reduce.)  Each virtual rank computes only its slab's [Gram | cross-product]; their sum (what ncclAllReduce forms) equals
     the single-rank buffer, and the numpy Gram/cross-product of the slab nnlm_shard_range() reports."""
+    monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
     rng = np.random.default_rng(world)
     n, m, k = 700, 300, 11
     A = rng.random((n, m))
@@ -372,11 +373,14 @@ def test_virtual_rank_partials_sum_to_the_unsharded_buffer(pname, prec, tol, wor
 
 
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
-def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
-    """The multi-GPU code path end to end on one GPU: a real RCCL communicator of size 1 makes the handle fold its slabs,
-    call ncclAllReduce, sweep its column slab into the packed buffer, call ncclAllGather and unpack.  With one rank every
+@pytest.mark.parametrize("form", ["cols", "reduce"])
+def test_sharded_path_with_a_real_one_rank_rccl_communicator(monkeypatch, pname, prec, tol, form):
+    """The multi-GPU code path end to end on one GPU, both forms of the dense half-step: a real RCCL communicator of size 1 makes
+    the handle (reduce) fold its slabs and call ncclAllReduce, (both) sweep its column slab into the packed buffer, call
+    ncclAllGather and unpack.  With one rank every
     collective is the identity, so the result must be bit-identical to the plain path in the strict mode (same reduction
     orders) and equal to rounding in the f32 mode."""
+    monkeypatch.setenv("NNLM_SHARD_DENSE", form)
     rng = np.random.default_rng(77)
     n, m, k = 300, 200, 9
     A = rng.random((n, m))
@@ -422,11 +426,12 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(pname, prec, tol):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("method", [1, 2])
 @pytest.mark.parametrize("k", [13, 50])  # 50: the tail-block form of the fast sweep on column slabs that do not start at 0
-def test_virtual_ranks_run_whole_sharded_half_steps(pname, prec, tol, world, method, k):
-    """Shard arithmetic of the multi-GPU path with `world` virtual ranks on one device: every rank contracts its slab
+def test_virtual_ranks_run_whole_sharded_half_steps(monkeypatch, pname, prec, tol, world, method, k):
+    """Shard arithmetic of the multi-GPU path's all-reduce form with `world` virtual ranks on one device: every rank contracts its slab
     (phase 1), the host stand-in for ncclAllReduce sums the [Gram | cross-product] buffers, every rank sweeps ITS columns
     (phase 2), the stand-in for ncclAllGather distributes the packed slabs, every rank unpacks (phase 3).  All ranks must
     end with identical factors, equal to the single-rank result up to the all-reduce's summation order."""
+    monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")
     rng = np.random.default_rng(world + method)
     n, m = 500, 333
     A = rng.random((n, m))
@@ -643,15 +648,16 @@ def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
 # ---- column-sharded half-steps (missing values, KL methods): all-gather only -------------------------------------------
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", ["na_scd", "na_lee", "kl_scd", "kl_lee", "na_kl_lee"])
+@pytest.mark.parametrize("case", ["dense_scd", "dense_lee", "dense_scd_k50", "na_scd", "na_lee", "kl_scd", "kl_lee", "na_kl_lee"])
 def test_virtual_ranks_run_column_sharded_half_steps(pname, prec, tol, world, case):
-    """With missing values (per-column Grams) and for the KL methods the column is the unit of the multi-GPU split: a rank does
+    """The column-sharded form -- the default for dense square loss, the only one with missing values (per-column Grams) and for the
+    KL methods: the column is the unit of the multi-GPU split, a rank does
     all the work of ITS columns (nnlm_shard_cols) over the whole contraction into a packed slab, ONE all-gather returns the
     factor, every rank unpacks -- no all-reduce.  `world` virtual ranks on one device, the host standing in for ncclAllGather;
     every rank must end with identical factors, equal to the single-rank result."""
-    method = {"na_scd": 1, "na_lee": 2, "kl_scd": 3, "kl_lee": 4, "na_kl_lee": 4}[case]
+    method = {"dense_scd": 1, "dense_lee": 2, "dense_scd_k50": 1, "na_scd": 1, "na_lee": 2, "kl_scd": 3, "kl_lee": 4, "na_kl_lee": 4}[case]
     rng = np.random.default_rng(world + method)
-    n, m, k = 700, 333, 13
+    n, m, k = 700, 333, (50 if case.endswith("k50") else 13)  # (50: the tail-block sweep on column slabs that do not start at 0)
     A = rng.random((n, 5)) @ rng.random((5, m)) + 0.1 * rng.random((n, m))
     if case.startswith("na"):
         A.ravel()[rng.choice(A.size, A.size // 10, replace=False)] = np.nan
