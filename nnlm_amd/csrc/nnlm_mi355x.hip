@@ -601,7 +601,6 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     if (!h || !h->A) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: set the matrix first");
     const int k = (int)k_;
     if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
-    if (k > NNLM_KQ_MAX && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "nnlm_set_factors: rank k=%d > %d is not sharded across GPUs in this build", k, NNLM_KQ_MAX);
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
     if (k != h->k) {
@@ -1534,7 +1533,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     h->sg_prev = sg_which;
     h->sg_which = h->sg_other = -1;
     h->sg_request = false;
-    if (generic_rank(h) && h->sharded) return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d is not sharded across GPUs in this build", NNLM_KQ_MAX);
+    if (generic_rank(h) && h->sharded && method < 3 && !h->any_missing && !h->dense_cols)
+        return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d across GPUs: only the column-sharded form (unset NNLM_SHARD_DENSE=reduce)", NNLM_KQ_MAX);
     if (partial_only) phase = PH_A;
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative, phase);
     // Missing values across GPUs: every column has a Gram of its own, so the column is the unit: a rank forms the
@@ -1560,7 +1560,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HalfPlan p = plan_half(h, which, colshard ? 0 : h->rank, colshard ? 1 : h->nranks);
     if (colshard) { // own columns only, whole contraction
         const ShardCols sc = shard_cols(h, (which == 1) ? h->m : h->n);
-        const int tile = (which == 1 || h->x16) ? XPROD_TN_BJ : 64 * (16 / (int)esize(h));
+        const int tile = (which == 1 || h->x16 || generic_rank(h)) ? XPROD_TN_BJ : 64 * (16 / (int)esize(h)); // (rank > 64: the TN kernel on A^T)
         p.col_off = sc.col0;
         p.tiles_x = (sc.col1 - sc.col0 + tile - 1) / tile;
         if (p.tiles_x > 0) split_plan(p.tiles_x, p.stage_end - p.stage_begin, &p.S, &p.sps);

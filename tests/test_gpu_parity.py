@@ -648,16 +648,20 @@ def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
 # ---- column-sharded half-steps (missing values, KL methods): all-gather only -------------------------------------------
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", ["dense_scd", "dense_lee", "dense_scd_k50", "na_scd", "na_lee", "kl_scd", "kl_lee", "na_kl_lee"])
+@pytest.mark.parametrize("case", ["dense_scd", "dense_lee", "dense_scd_k50", "dense_scd_k80", "na_scd", "na_lee", "na_scd_k80", "kl_scd", "kl_lee",
+                                  "kl_lee_k80", "na_kl_lee"])
 def test_virtual_ranks_run_column_sharded_half_steps(pname, prec, tol, world, case):
     """The column-sharded form -- the default for dense square loss, the only one with missing values (per-column Grams) and for the
     KL methods: the column is the unit of the multi-GPU split, a rank does
     all the work of ITS columns (nnlm_shard_cols) over the whole contraction into a packed slab, ONE all-gather returns the
     factor, every rank unpacks -- no all-reduce.  `world` virtual ranks on one device, the host standing in for ncclAllGather;
     every rank must end with identical factors, equal to the single-rank result."""
-    method = {"dense_scd": 1, "dense_lee": 2, "dense_scd_k50": 1, "na_scd": 1, "na_lee": 2, "kl_scd": 3, "kl_lee": 4, "na_kl_lee": 4}[case]
+    import re
+    base, kk = re.fullmatch(r"(.*?)(?:_k(\d+))?", case).groups()
+    method = {"dense_scd": 1, "dense_lee": 2, "na_scd": 1, "na_lee": 2, "kl_scd": 3, "kl_lee": 4, "na_kl_lee": 4}[base]
     rng = np.random.default_rng(world + method)
-    n, m, k = 700, 333, (50 if case.endswith("k50") else 13)  # (50: the tail-block sweep on column slabs that do not start at 0)
+    # (k = 50: the tail-block sweep on column slabs that do not start at 0; 80: the rank > 64 kernels, k_generic.h)
+    n, m, k = 700, 333, (int(kk) if kk else 13)
     A = rng.random((n, 5)) @ rng.random((5, m)) + 0.1 * rng.random((n, m))
     if case.startswith("na"):
         A.ravel()[rng.choice(A.size, A.size // 10, replace=False)] = np.nan
