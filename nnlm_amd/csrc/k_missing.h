@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         if (4 * g + drow >= ulen) row = ri.a;
         const unsigned voff = (unsigned)row * (unsigned)(KP * 4) + (unsigned)dch * 16u;
         const unsigned dst = lds0 + (unsigned)(g & (STG - 1)) * (unsigned)(SF * 4);
-        if (dact) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst) : "memory", "m0");
+        if (dact) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst) : "memory");
     };
     struct Row {
         float x[NT];
