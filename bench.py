@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TF = 78.6        # fp64 vector = matrix peak
+FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_*_f32, dense (MI355X_MICROARCH.md)
 # KL solvers: 3 plain + 1 transcendental fp32 instruction per element and coordinate = 14.9 cycles per 64 elements per SIMD
 # measured in isolation (scripts/exp/valu_exp.hip, "KL body packed"): 1024 SIMDs x 64 / 14.9 x 2.4 GHz
 KL_PEAK_GELEM = 1024 * 64 / 14.9 * 2.4
@@ -260,9 +261,12 @@ def main():
                 knm = "na_gram_lds_kernel + colsolve_fast_kernel" if cfg["na"] else "sweep_scd_wgf_kernel"
                 if cfg["na"]:
                     fl += 2.0 * k * k * (n * m // 10)  # per-column Grams over the complement rows (2 k^2 per missing entry)
-                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=FP64_PEAK_TF, unit="TFLOP/s", scale=1e12, pmc=None,
+                # missing values, F32 mode: 95 % of these flops are the per-column Grams on v_mfma_f32_16x16x4_f32 -> the fp32 matrix peak
+                pk = FP32_MFMA_PEAK_TF if (cfg["na"] and s == 4) else FP64_PEAK_TF
+                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None,
                                    note="latency bound: inner*k dependent coordinate steps per column; flops = inner*cols*k*(2k+8)"
-                                        + (" + 2k^2 per missing entry (per-column Grams)" if cfg["na"] else ""))
+                                        + (" + 2k^2 per missing entry (per-column Grams, fp32 MFMA in the F32 mode: priced against the fp32 "
+                                           "matrix peak; the scope's time also holds the per-column solver)" if cfg["na"] else ""))
     else:
         for nm in ("sweep_h", "sweep_w"):
             if kern[nm]["ms_per_launch"]:
