@@ -150,6 +150,38 @@ def test_config5_full_size_one_iteration():
     assert d_ep <= 0.5
 
 
+@pytest.mark.parametrize("name,method,na,iters", [("config3_lee_mkl_5_iterations", 4, False, 5), ("config5_na_reg_4_iterations", 1, True, 4)])
+def test_configs_3_and_5_full_size_drift_over_iterations(name, method, na, iters):
+    """BASELINE configs[2] and configs[4] a few outer iterations deep through nnlm_run (R defaults for the loss; trace = 1 so that
+    every iteration's error block is compared): the drift of the F32 mode against the oracle, measured and reported."""
+    A, W0, H0 = inputs()
+    if na:
+        A = A.copy()
+        A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+    reg = [0.01, 0.0, 0.01] if na else [0.0, 0.0, 0.0]
+    inner = 50 if method < 3 else 1
+    with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
+        h.set_matrix(A)
+        h.set_factors(K, W0, H0)
+        r = h.run(reg, reg, iters, -1.0, 0, False, inner, 1e-9, method, 1)
+        W, H = h.get_factors()
+    t0 = time.perf_counter()
+    o = ref.c_nnmf(A, K, W0, H0, None, None, reg, reg, iters, -1.0, 0, 0, False, inner, 1e-9, method, 1)
+    t_or = time.perf_counter() - t0
+    ew, eh = relF(W, o["W"]), relF(H, o["H"])
+    d_mse = float(np.max(np.abs(r["mse_error"] - o["mse_error"]) / o["mse_error"]))
+    d_mkl = float(np.max(np.abs(r["mkl_error"] - o["mkl_error"]) / np.abs(o["mkl_error"])))
+    d_tgt = float(np.max(np.abs(r["target_error"] - o["target_error"]) / np.abs(o["target_error"])))
+    d_ep = float(np.max(np.abs(r["average_epoch"] - o["average_epoch"])))
+    report(name, relF_W=ew, relF_H=eh, max_rel_mse_trace=d_mse, max_rel_mkl_trace=d_mkl, max_rel_target_trace=d_tgt, max_abs_epoch_trace=d_ep,
+           oracle_seconds=t_or, n_trace=len(r["mse_error"]))
+    assert r["n_iteration"] == o["n_iteration"] == iters and len(r["mse_error"]) == len(o["mse_error"]) == iters
+    assert ew < 1e-4 and eh < 1e-4, (ew, eh)
+    assert d_mse < 1e-5 and d_mkl < 1e-5 and d_tgt < 1e-5, (d_mse, d_mkl, d_tgt)
+    assert d_ep <= 0.5
+    assert np.all(W >= 0) and np.all(H >= 0)
+
+
 @pytest.mark.parametrize("seed,shape", [(1, (600, 400, 10)), (2, (900, 300, 8)), (3, (350, 500, 12))])
 def test_f32_mode_stops_at_the_iteration_the_oracle_stops(seed, shape):
     """The stopping rule (|rel_err| <= rel.tol = 1e-4, evaluated on trace iterations, src/nnmf.cpp:109,153) in the F32
