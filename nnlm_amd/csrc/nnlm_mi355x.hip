@@ -1968,7 +1968,8 @@ extern "C" int nnlm_sync(nnlm_handle *h)
 // `with_sweeps`, the active sweep counter land in the pinned host_res[0..8]; ev_err fires when they are there.
 // fused_nb > 0: the two sums were left as fused_nb partial pairs in h->partials by the cross product of the speculative
 // W half-step (xprod16_err_kernel); only their reduction, the penalties and the counters remain.
-static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb = 0)
+// need_pen: the six penalty sums of add_penalty() -- nnlm_run skips them when alpha = beta = 0 (penalties() then uses none of them)
+static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb = 0, bool need_pen = true)
 {
     const int k4 = round_up_i(h->k, 4);
     if (fused_nb > 0) {
@@ -2019,11 +2020,13 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
             if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (error sums) failed");
         }
     }
-    const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
-    penalty_kernel<<<nbw, 256, 0, st>>>(h->W64, h->npad, h->n, h->k, h->partials);
-    reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
-    penalty_kernel<<<nbh, 256, 0, st>>>(h->H64, h->mpad, h->m, h->k, h->partials);
-    reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
+    if (need_pen) {
+        const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
+        penalty_kernel<<<nbw, 256, 0, st>>>(h->W64, h->npad, h->n, h->k, h->partials);
+        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
+        penalty_kernel<<<nbh, 256, 0, st>>>(h->H64, h->mpad, h->m, h->k, h->partials);
+        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
+    }
     HIPCHK(h, hipMemcpyAsync(h->host_res, h->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (with_sweeps) {
         const unsigned long long *src = h->sweeps + h->sw_active;
@@ -2280,6 +2283,8 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         cb_print(cb, "--------------------------------------------------------------\n");
     }
 
+    // the six penalty sums are read by penalties() only through these conditions (src/nnmf.cpp:224-240)
+    const bool need_pen = alpha[0] != alpha[1] || beta[0] != beta[1] || alpha[1] != 0 || beta[1] != 0 || alpha[2] != 0 || beta[2] != 0;
     double rel_err = rel_tol + 1, terr_last = 1e99;
     unsigned i = 0, i_e = 0;
     auto book = [&](unsigned it, double mse, double kl, const double pen[6], long long raw) {
@@ -2351,7 +2356,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 spec.pending = true;
             } else
                 h->fused_nb = 0;
-            CHK(errors_launch(h, h->stream_e, true, h->fused_nb)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            CHK(errors_launch(h, h->stream_e, true, h->fused_nb, need_pen)); // reads W_i, H_i and the active sweep counter (then zeroes it)
             h->fused_nb = 0;
             // H (and the fp32 copy the error kernel reads) must not be rewritten before the error block is done
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_err, 0));
