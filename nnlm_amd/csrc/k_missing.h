@@ -613,6 +613,142 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
     }
 }
 
+// Per-column Gram of the fp32-operand mode on the fp16 matrix cores: the listed rows come as SPLIT fp16 pairs (hi + lo 2^-11, 22
+// bits, scaled by a power of two: the cross products' representation, factor16c_kernel: row = 64 hi halves | 64 lo halves = 256 B),
+// 32 rows per step, and  sum_r y_r y_r^T  over a step is  Hi Hi^T + (Hi Lo^T + Lo Hi^T) 2^-11  on v_mfma_f32_16x16x32_f16:
+// 3 products per upper tile pair, 16 cycles each for 32 rows -- 60 cycles of matrix pipe per four rows against 192 (tail form) /
+// 320 (padded) for v_mfma_f32_16x16x4_f32, and one set of index / address / LDS instructions per 32 rows instead of per 4.
+//   * gather: 8 global_load_lds_dwordx4 per step, one per 1 KB subtile [32 rows][16 halves] (plane hi / lo x coordinate tile):
+//     lane l fetches 16 bytes of row l / 2 -- the LDS image is the row-major [k][16] subtile ds_read_b64_tr_b16 wants (MFMA operand
+//     = 8 halves along k for the lane's coordinate: two transpose reads, conflict free);
+//   * row indices: one global_load_lds_dword per step (lane l: entry l / 2 of the step) into a 256-byte ring slot, read back with
+//     ds_read_b32 -- no VGPR destination, no compiler-visible VMEM: a step is "s_waitcnt vmcnt(0); issue the next step's gathers;
+//     multiply this step" with two 8 KB stage buffers per wavefront;
+//   * rows past the end of the list read row p of the split copy, which factor16c_kernel leaves zero;
+//   * fp32 accumulators folded into fp64 every 8 steps (256 rows), unscaled by 2^-2e at the end (e: the split copy's exponent).
+// The correction is ~the missing fraction of G, so 22-bit products keep G_j at ~1e-8 relative, as the fp32 form did.
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+template <int NKQ>
+__global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
+                                                          const uint32_t *__restrict__ Y16rows, int zero_row, const int *__restrict__ exp_in,
+                                                          const double *__restrict__ Gfull, double *__restrict__ Gcols, int ncols, int col0, int k)
+{
+    constexpr int KP = 16 * NKQ;          // row stride of Gfull / Gcols
+    constexpr int NP = NKQ * (NKQ + 1) / 2;
+    constexpr int STAGE = 8 * 1024;        // bytes: 2 planes x 4 coordinate tiles x [32][16] halves (the split copy always has 64 coordinates)
+    __shared__ __attribute__((aligned(16))) unsigned char stage_all[4][2][STAGE];
+    __shared__ int ibuf_all[4][2][64];
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
+    const int col = col0 + blockIdx.x * 4 + wave;
+    if (col >= ncols) return; // whole wave
+    const uint32_t mt = meta[col];
+    const int ulen = __builtin_amdgcn_readfirstlane((int)(mt & 0x7FFFFFFFu));
+    const bool complement = (mt >> 31) != 0;
+    const int base = __builtin_amdgcn_readfirstlane((int)ptr[col]);
+    unsigned char *stage = &stage_all[wave][0][0];
+    int *ibuf = &ibuf_all[wave][0][0];
+
+    f32x4 accm[NP], accx[NP];
+    f64x4 acc64[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) accm[i] = accx[i] = f32x4{0, 0, 0, 0}, acc64[i] = f64x4{0, 0, 0, 0};
+
+    const int nst = (ulen + 31) >> 5; // steps of 32 rows
+    auto sbase = [&](const void *q) { // 64-bit pointer as an SGPR pair
+        const unsigned long long v = (unsigned long long)q;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    const unsigned long long ybase = sbase(Y16rows), ibase = sbase(idx + base);
+    const unsigned lds_stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)stage);
+    const unsigned lds_ibuf = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) int *)ibuf);
+    const int r2 = lane >> 1; // row of the step this lane gathers
+    auto issue_idx = [&](int g) { // entries 32 g + lane / 2 of the list (the list array carries 64 words of slack) -> ring slot g & 1
+        const unsigned voff = (unsigned)(32 * g + r2) * 4u;
+        const unsigned dst = lds_ibuf + (unsigned)(g & 1) * 256u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(ibase), "s"(dst) : "memory");
+    };
+    auto issue_rows = [&](int g) { // the eight subtiles of step g into stage buffer g & 1
+        int row = ibuf[(g & 1) * 64 + lane];
+        if (32 * g + r2 >= ulen) row = zero_row;
+        const unsigned voff = (unsigned)row * 256u + (unsigned)(lane & 1) * 16u;
+        const unsigned dst = lds_stage + (unsigned)(g & 1) * (unsigned)STAGE;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { // subtile j = plane (j >> 2), coordinate tile (j & 3): bytes plane * 128 + tile * 32 of the row
+            // (the instruction offset is added to the global address AND to the LDS address: M0 is set back by it)
+            const unsigned off = (unsigned)((j >> 2) * 128 + (j & 3) * 32);
+            if ((j & 3) < NKQ)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(ybase),
+                             "s"(dst + (unsigned)j * 1024u - off), "n"((j >> 2) * 128 + (j & 3) * 32)
+                             : "memory");
+        }
+    };
+    if (nst > 0) {
+        issue_idx(0);
+        issue_idx(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_rows(0);
+        // operand (plane pl, tile t) of the lane: halves k = 8 lg .. 8 lg + 7 of coordinate 16 t + l15: two transpose reads of
+        // [4 rows][16 halves] blocks, lane (4 j + i) of a 16-lane group addressing row j, halves 4 i .. 4 i + 3
+        const unsigned tr_lane = (unsigned)(8 * lg + (l15 >> 2)) * 32u + (unsigned)(l15 & 3) * 8u;
+        int since = 0;
+        for (int g = 0; g < nst; g++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // rows of step g and indices of step g + 1 have landed
+            issue_idx(g + 2);                                 // (slot g & 1: its entries were consumed one step ago)
+            issue_rows(g + 1);                                // (past the end: zero rows into the other buffer, never multiplied)
+            const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)stage + (unsigned)(g & 1) * (unsigned)STAGE + tr_lane;
+            gh8 hi[NKQ], lo[NKQ];
+#pragma unroll
+            for (int t = 0; t < NKQ; t++) {
+                gh4 a0, a1, b0, b1;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a0) : "v"(sb), "n"(t * 1024));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a1) : "v"(sb), "n"(t * 1024 + 128));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b0) : "v"(sb), "n"(4096 + t * 1024));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b1) : "v"(sb), "n"(4096 + t * 1024 + 128));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                hi[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                lo[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            int pi = 0;
+#pragma unroll
+            for (int a = 0; a < NKQ; a++)
+#pragma unroll
+                for (int b = a; b < NKQ; b++, pi++) {
+                    accm[pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[a], hi[b], accm[pi], 0, 0, 0);
+                    accx[pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[a], lo[b], accx[pi], 0, 0, 0);
+                    accx[pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo[a], hi[b], accx[pi], 0, 0, 0);
+                }
+            if (++since == 8) { // 256 rows
+                since = 0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc64[i][r] += (double)accm[i][r] + (double)accx[i][r] * (1.0 / 2048.0);
+                    accm[i] = accx[i] = f32x4{0, 0, 0, 0};
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (nothing may land in LDS after the wavefront has gone)
+    }
+    const double unscale = ldexp(1.0, -2 * exp_in[0]);
+    double *out = Gcols + (size_t)col * KP * KP;
+    int pi = 0;
+#pragma unroll
+    for (int a = 0; a < NKQ; a++)
+#pragma unroll
+        for (int b = a; b < NKQ; b++, pi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * a + 4 * lg + r, j = 16 * b + l15; // C/D layout of the 16x16 fp32 tile: row 4 (lane >> 4) + r, column lane & 15
+                if (i < k && j < k) {                                // (entries beyond k are never read by the solvers)
+                    const double sum = (acc64[pi][r] + (double)accm[pi][r] + (double)accx[pi][r] * (1.0 / 2048.0)) * unscale;
+                    const double v = complement ? Gfull[i * KP + j] - sum : sum;
+                    out[i * KP + j] = v;
+                    if (a != b) out[j * KP + i] = v;
+                }
+            }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // colsolve_fast_kernel -- SCD-LS with a Gram of its own per column (or one shared Gram), fp32-operand mode (k <= 64).
 //

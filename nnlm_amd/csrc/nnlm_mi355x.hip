@@ -1268,12 +1268,21 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
     if (total >= 0x7FFFFFFFull) return fail(h, NNLM_ERR_UNSUPPORTED, "missing-value row lists exceed 2^31 entries");
     HIPCHK(h, hipMalloc(&h->na_ptr[which], (size_t)(ncols + 1) * 4));
     HIPCHK(h, hipMalloc(&h->na_meta[which], (size_t)ncols * 4));
-    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 16) * 4)); // (+16: na_gram_lds_kernel loads whole groups of four indices ahead)
+    HIPCHK(h, hipMalloc(&h->na_idx[which], (total + 128) * 4)); // (slack: the Gram kernels request whole groups / steps of indices ahead of the end)
     HIPCHK(h, hipMemcpyAsync(h->na_ptr[which], hptr.data(), (size_t)(ncols + 1) * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->na_meta[which], hmeta.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, h->stream));
     na_fill_kernel<<<ncols, 256, 0, h->stream>>>(bits, words, p, h->na_ptr[which], h->na_meta[which], h->na_idx[which]);
     HIPCHK(h, hipStreamSynchronize(h->stream)); // hptr / hmeta go out of scope
     return NNLM_OK;
+}
+
+// Row-major copy of the fixed factor the NA / KL-with-NA paths gather from: [p][KP] doubles or floats, or -- split-fp16 Grams --
+// [p + 64][64 hi | 64 lo halves] (256 bytes per row whatever KP is; the rows behind p are zero)
+static size_t yrow_bytes(const nnlm_handle *h)
+{
+    const size_t big = (size_t)(h->npad > h->mpad ? h->npad : h->mpad);
+    const size_t a = big * h->KP * 8, b = (big + 64) * 256;
+    return a > b ? a : b;
 }
 
 // NNLM_NA_GRAM=valu keeps the VALU kernel (A/B).  Per-column Grams of columns [c0, c1) (row lists exist for all ncols columns)
@@ -1286,6 +1295,26 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
     const int ldy = (which == 1) ? h->npad : h->mpad;
     static int g32 = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "f64") == 0) ? 0 : 1;
     const bool f32rows = use_mfma && !generic_rank(h) && h->prec == NNLM_PREC_F32 && g32;
+    // F32 mode with split-fp16 cross products: the Grams on the fp16 matrix cores from the split copy of the rows (na_gram_f16_kernel).
+    // max|fixed factor| is in maxbits[0] (prepare_factor16 ran for this half-step's cross product).  NNLM_NA_GRAM_F16=0: fp32 rows.
+    static int f16_env = getenv("NNLM_NA_GRAM_F16") ? atoi(getenv("NNLM_NA_GRAM_F16")) : 1;
+    const bool f16rows = f32rows && h->x16 && f16_env;
+    if (f16rows) {
+        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
+        if (rc != NNLM_OK) return rc;
+        // [p + 64 rows][64 hi | 64 lo halves]; rows p .. are zero (the kernel's "no row" index)
+        factor16c_kernel<<<p / 64 + 1, 256, 0, h->stream>>>(Ym, ldy, p, h->k, h->maxbits, h->scal_exp + 3, (uint32_t *)h->Yrow);
+        const int nb = (nc + 3) / 4;
+#define NNLM_NAGH(N_) na_gram_f16_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const uint32_t *)h->Yrow, p, h->scal_exp + 3, h->Graw, h->Gcols, c1, c0, h->k)
+        switch (h->NKQ) {
+        case 1: NNLM_NAGH(1); break;
+        case 2: NNLM_NAGH(2); break;
+        case 3: NNLM_NAGH(3); break;
+        default: NNLM_NAGH(4); break;
+        }
+#undef NNLM_NAGH
+        return NNLM_OK;
+    }
     if (f32rows) factor_rows_kernel<float><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, (float *)h->Yrow);
     else factor_rows_kernel<double><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, h->Yrow);
     if (generic_rank(h)) { // rank > 64: k_generic.h
@@ -1472,8 +1501,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ta.sumw_cols = nullptr;
         ta.ldsw = h->KP;
         if (h->any_missing) { // row sums over each column's non-missing entries (src/update_with_missing.cpp:122,130)
-            const int big = h->npad > h->mpad ? h->npad : h->mpad;
-            if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
+            if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, yrow_bytes(h)));
             if (!h->klsw_cols) HIPCHK(h, hipMalloc(&h->klsw_cols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * 8));
             int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, ncols_all);
             if (rc != NNLM_OK) return rc;
@@ -1553,8 +1581,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, pp.S, speculative, phase, colshard);
     }
     if (h->any_missing && !h->Gcols) { // NA path workspaces, on first use
-        const int big = h->npad > h->mpad ? h->npad : h->mpad;
-        HIPCHK(h, hipMalloc(&h->Yrow, (size_t)big * h->KP * 8));
+        if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, yrow_bytes(h)));
         HIPCHK(h, hipMalloc(&h->Gcols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * h->KP * 8));
     }
     HalfPlan p = plan_half(h, which, colshard ? 0 : h->rank, colshard ? 1 : h->nranks);
