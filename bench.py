@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TF = 78.6        # fp64 vector = matrix peak
-FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_*_f32, dense (MI355X_MICROARCH.md)
+FP16_MFMA_PEAK_TF = 2500.0 # v_mfma_f32_16x16x32_f16 / bf16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 # KL solvers: 3 plain + 1 transcendental fp32 instruction per element and coordinate = 14.9 cycles per 64 elements per SIMD
 # measured in isolation (scripts/exp/valu_exp.hip, "KL body packed"): 1024 SIMDs x 64 / 14.9 x 2.4 GHz
 KL_PEAK_GELEM = 1024 * 64 / 14.9 * 2.4
@@ -258,15 +258,22 @@ def main():
                 # the sweeps are a loop-carried recurrence (SURVEY 8d grants them no HBM/MFMA roofline): priced as achieved fp64
                 # arithmetic of the recurrence, inner*cols*k*(2k+8) flops per launch, against the fp64 matrix/vector peak
                 fl = inner * (cols / world) * k * (2 * k + 8)
-                knm = "na_gram_lds_kernel + colsolve_fast_kernel" if cfg["na"] else "sweep_scd_wgf_kernel"
+                knm = "na_gram_f16_kernel + colsolve_fast_kernel" if cfg["na"] else "sweep_scd_wgf_kernel"
+                pk = FP64_PEAK_TF
+                note = "latency bound: inner*k dependent coordinate steps per column; flops = inner*cols*k*(2k+8)"
                 if cfg["na"]:
-                    fl += 2.0 * k * k * (n * m // 10)  # per-column Grams over the complement rows (2 k^2 per missing entry)
-                # missing values, F32 mode: 95 % of these flops are the per-column Grams on v_mfma_f32_16x16x4_f32 -> the fp32 matrix peak
-                pk = FP32_MFMA_PEAK_TF if (cfg["na"] and s == 4) else FP64_PEAK_TF
-                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None,
-                                   note="latency bound: inner*k dependent coordinate steps per column; flops = inner*cols*k*(2k+8)"
-                                        + (" + 2k^2 per missing entry (per-column Grams, fp32 MFMA in the F32 mode: priced against the fp32 "
-                                           "matrix peak; the scope's time also holds the per-column solver)" if cfg["na"] else ""))
+                    # + the per-column Grams over the complement rows, 2 k^2 flops per missing entry.  F32 mode: they run on the fp16 matrix
+                    # cores as three split-fp16 products (a third of the dense fp16 peak per algorithmic flop); strict mode: fp64 MFMA.
+                    # The scope holds both kernels, so the peak is the blend that gives frac = (t_gram_floor + t_solver_floor) / t_measured.
+                    gfl = 2.0 * k * k * (n * m // 10)
+                    gpk = FP16_MFMA_PEAK_TF / 3.0 if s == 4 else FP64_PEAK_TF
+                    floor_s = gfl / (gpk * 1e12) + fl / (FP64_PEAK_TF * 1e12)
+                    fl += gfl
+                    pk = fl / floor_s / 1e12
+                    note += (" (fp64 vector peak) + 2k^2 per missing entry for the per-column Grams ("
+                             + ("3 split-fp16 products per flop on v_mfma_f32_16x16x32_f16: a third of the 2.5 PF dense fp16 peak" if s == 4 else "fp64 MFMA peak")
+                             + "); peak = total flops / (sum of the two floors)")
+                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None, note=note)
     else:
         for nm in ("sweep_h", "sweep_w"):
             if kern[nm]["ms_per_launch"]:
