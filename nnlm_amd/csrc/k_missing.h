@@ -765,7 +765,9 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 // Results differ from colsolve_ls_kernel by rounding only (the deviations listed for k_sweep_wgf.h in DESIGN.md section 2).
 // Also the dense sweep for SMALL column counts (multi-GPU column shards): its duration is 2500 steps x ~40 cycles however
 // few columns there are, a quarter of the workgroup-specialised kernel's.
-template <int NKQ, bool HAS_MASK>
+// KR: coordinates with a register of the Gram row (k <= KR <= 16 NKQ): k = 50 takes 52 instead of 64 -- 123 instead of 147 VGPRs, four
+// instead of three wavefronts per SIMD.
+template <int NKQ, bool HAS_MASK, int KR = 16 * NKQ>
 __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, size_t g_stride)
 {
     constexpr int KP = 16 * NKQ;
@@ -789,9 +791,9 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
         gd += NNLM_TINY;
     }
     const double rgd = 1.0 / gd;
-    double gs[KP]; // row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
+    double gs[KR]; // row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
 #pragma unroll
-    for (int q = 0; q < KP; q++) {
+    for (int q = 0; q < KR; q++) {
         double v = 0.0;
         if (q < k && lv) {
             v = G[(size_t)q * a.KPg + lane];
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
     // nu = (G x - c + L1) / G[lane][lane]
     double nu = lv ? (((a.r2 != 0) ? a.r2 - cv : -cv) * rgd) : 0.0;
 #pragma unroll
-    for (int q = 0; q < KP; q++)
+    for (int q = 0; q < KR; q++)
         if (q < k) nu = __builtin_fma(readlane_f64(x, q), gs[q], nu);
 
     unsigned t = 0;
@@ -832,13 +834,14 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
             };
 #pragma unroll
             for (int c = 0; c < NKQ; c++) {
-                if (!HAS_MASK && 16 * c + 16 <= kk) { // a whole block of 16 coordinates: no per-step test
+                if (!HAS_MASK && 16 * c + 16 <= KR && 16 * c + 16 <= kk) { // a whole block of 16 coordinates: no per-step test
 #pragma unroll
                     for (int e = 0; e < 16; e++) step(16 * c + e);
                 } else if (16 * c < kk) {
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
+                        if (16 * c + e < KR) // (compile time)
+                            if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
                 }
             }
             const double xn = x + xd;

@@ -1204,6 +1204,12 @@ static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStrea
 {
     const int nb = (a.ncols - a.col0 + 3) / 4;
     if (nb <= 0) return;
+    constexpr int KS = NKQ > 1 ? 16 * (NKQ - 1) + 4 : 16; // k = 16 j + 1 .. 16 j + 4: a Gram row of 16 j + 4 registers (k = 50: 52)
+    if (NKQ > 1 && a.k <= KS) {
+        if (a.mask) colsolve_fast_kernel<NKQ, true, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        else colsolve_fast_kernel<NKQ, false, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        return;
+    }
     if (a.mask) colsolve_fast_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
     else colsolve_fast_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
 }
