@@ -645,6 +645,36 @@ def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
             assert (s1, s2) == (it1, it2)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_small_shapes_with_missing_values(seed):
+    """Randomised edge sweep of the NA path (row lists shorter than one gather step, contraction lengths below one tile, ranks that
+    use every instantiation of the Gram / solver kernels, 0 - 90 % missing, all-missing columns): both half-steps against the oracle
+    in both modes."""
+    rng = np.random.default_rng(9000 + seed)
+    n, m = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+    k = int(rng.integers(1, 65))
+    rate = [0.02, 0.1, 0.5, 0.9][seed % 4]
+    method = 1 + (seed // 4) % 2
+    A = rng.random((n, m)) + 0.05
+    A[rng.random((n, m)) < rate] = np.nan
+    if not np.isnan(A).any():
+        A[0, 0] = np.nan
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    reg = [0.05, 0.01, 0.02]
+    for prec, tol in ((_lib.PREC_F64, 1e-9), (_lib.PREC_F32, 1e-4)):
+        with nnlm_amd.Handle(0, prec) as h:
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0)
+            h.half_step(1, reg, 3, 1e-9, method)
+            _, H1 = h.get_factors()
+            H_ref, _ = ref.update(H0, W0.T.copy(), A, None, reg, 3, 1e-9, method)
+            assert relF(H1, H_ref) < tol, (n, m, k, rate, method, prec)
+            h.half_step(0, reg, 3, 1e-9, method)
+            W1, _ = h.get_factors()
+            Wt_ref, _ = ref.update(W0.T.copy(), H_ref, A.T.copy(), None, reg, 3, 1e-9, method)
+            assert relF(W1, Wt_ref.T) < 10 * tol, (n, m, k, rate, method, prec)
+
+
 # ---- column-sharded half-steps (missing values, KL methods): all-gather only -------------------------------------------
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3])
