@@ -89,13 +89,17 @@ def test_golden_halfstep_fixtures(pname, prec, tol):
             assert it == int(z[key + "_it"]), key
 
 
+@pytest.mark.parametrize("missing", [False, True])
 @pytest.mark.parametrize("scale_a,scale_f", [(1e20, 1e-10), (1e-6, 1e3), (3.7e5, 1.0), (1.0, 2.3e-4)])  # Grams stay >> TINY_NUM
-def test_half_step_is_insensitive_to_the_magnitudes_of_A_and_the_factors(scale_a, scale_f):
+def test_half_step_is_insensitive_to_the_magnitudes_of_A_and_the_factors(scale_a, scale_f, missing):
     """The F32 mode's split-fp16 cross products rescale A (once) and the fixed factor (every half-step) by powers of two
-    (k_xprod16.h): matrices and factors far outside the fp16 range must give the same relative accuracy as O(1) data."""
+    (k_xprod16.h): matrices and factors far outside the fp16 range must give the same relative accuracy as O(1) data.  With missing
+    entries the per-column Grams run on the same split copy of the factor rows (k_missing.h, na_gram_f16_kernel)."""
     rng = np.random.default_rng(77)
     n, m, k = 300, 200, 20
     A = scale_a * rng.random((n, m)) ** 2
+    if missing:
+        A[rng.random((n, m)) < 0.15] = np.nan
     W0 = np.sqrt(scale_a) / scale_f * rng.random((n, k))
     H0 = scale_f * np.sqrt(scale_a) * rng.random((k, m))
     for prec, tol in ((_lib.PREC_F32, 2e-5), (_lib.PREC_F64, 1e-10)):
