@@ -247,14 +247,18 @@ __global__ __launch_bounds__(256) void errors_f32_kernel(const float *__restrict
 // What[j][i] = sum_q W[q][i] H[q][j] in fp32, stored in the layout of A ([mpad][lda]): the starting state vectors
 // y = Yt^T x of ALL columns of a KL half-step (src/base_algorithms.cpp:81, :129) as one GEMM instead of k passes over the
 // fixed factor per column (k_kl.h).  Same tiling and MFMA phase as errors_f32_kernel.
+// Grid: 1-D, 8 * ceil(nx / 8) * ny blocks in the XCD-aware order of errors_f32_kernel (an XCD keeps its eighth of the W slices in L2).
 __global__ __launch_bounds__(256) void wh_store_kernel(const float *__restrict__ Wf, int ldw, const float *__restrict__ Hf, int ldh, int k2,
-                                                       float *__restrict__ What, int lda)
+                                                       float *__restrict__ What, int lda, int nx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_err[];
     float *Ws = (float *)smem_err;          // [k2][128]
     float *Hs = Ws + (size_t)k2 * ERRF_TILE; // [k2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * ERRF_TILE, j0 = blockIdx.y * ERRF_TILE;
+    const int per = (nx + 7) >> 3;
+    const int bid = blockIdx.x, it = ((bid >> 3) % per) * 8 + (bid & 7), jt = (bid >> 3) / per;
+    if (it >= nx) return;
+    const int i0 = it * ERRF_TILE, j0 = jt * ERRF_TILE;
     const int l31 = lane & 31, lh = lane >> 5;
     const int ib = 64 * (wave & 1), jb = 64 * (wave >> 1);
     {

@@ -1478,15 +1478,15 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
         hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (which == 1) {
-            dim3 grid(h->npad / ERRF_TILE, h->mpad / ERRF_TILE);
-            wh_store_kernel<<<grid, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad);
+            const int nx = h->npad / ERRF_TILE, ny = h->mpad / ERRF_TILE;
+            wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad, nx);
             ta.Adata = (const float *)h->A;
             ta.Yf = (const float *)h->Wop;
         } else { // roles swapped: What^T [row of A][column of A], next to the transposed fp32 copy of A
             int rc = ensure_AT(h);
             if (rc != NNLM_OK) return rc;
-            dim3 grid(h->mpad / ERRF_TILE, h->npad / ERRF_TILE);
-            wh_store_kernel<<<grid, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop, h->npad, k2, h->What, h->mpad);
+            const int nx = h->mpad / ERRF_TILE, ny = h->npad / ERRF_TILE;
+            wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop, h->npad, k2, h->What, h->mpad, nx);
             ta.Adata = (const float *)h->AT;
             ta.Yf = h->Hkq;
         }
