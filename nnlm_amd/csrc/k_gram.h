@@ -152,18 +152,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restri
 // packed [nranks][KP][cpr] with KP = the rows that travelled (the caller passes k: the padding rows of a slab are not gathered);
 // rank rr holds columns rr*cpr .. of the factor; X [KP][ldx] master; op = GEMM operand copy
 // (op_mode 1: [KP][op_ld] same layout as X, 2: [col][op_ld] kq fastest, 0: none), element type float or double.
+// maxw (optional): max |x| over the factor as the bit pattern of a float (what absmax_f64_kernel computes), for the split-fp16 copy of
+// the NEXT half-step, whose fixed factor this is -- the unpack reads every entry anyway.  Zeroed by the caller.
 __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KP, int cpr, int k,
                                                            int ncols, double *__restrict__ X, int ldx, void *__restrict__ op,
-                                                           int op_mode, int op_ld, int op_f64)
+                                                           int op_mode, int op_ld, int op_f64, unsigned *__restrict__ maxw)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t per_rank = (size_t)KP * cpr;
-    if (e >= per_rank * nranks) return;
-    const int rr = (int)(e / per_rank);
-    const int q = (int)((e % per_rank) / cpr), lc = (int)(e % cpr);
-    const int col = rr * cpr + lc;
-    if (q >= k || col >= ncols) return;
-    const double v = packed[e];
+    float mx = 0.0f;
+    bool live = e < per_rank * nranks;
+    int q = 0, col = 0;
+    if (live) {
+        const int rr = (int)(e / per_rank);
+        q = (int)((e % per_rank) / cpr);
+        col = rr * cpr + (int)(e % cpr);
+        live = q < k && col < ncols;
+    }
+    const double v = live ? packed[e] : 0.0;
+    if (maxw) { // (whole wavefronts stay together for the reduction)
+        mx = fabsf((float)v);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxw, __float_as_uint(mx));
+    }
+    if (!live) return;
     X[(size_t)q * ldx + col] = v;
     if (op_mode == 1) {
         if (op_f64) ((double *)op)[(size_t)q * op_ld + col] = v;

@@ -61,6 +61,8 @@ struct nnlm_handle {
     uint32_t *missT = nullptr;  // [npad][mpad/32], only when any_missing
     bool any_missing = false;
     bool dense_cols = true;     // multi-GPU form of the dense square-loss half-step (half_step): column-sharded (true) or all-reduce
+    int upk_max_for = -1;       // multi-GPU: the half-step (0: W, 1: H) whose unpack left max|factor| in maxbits[6 + which], or -1
+    unsigned *fixed_maxw = nullptr; // word holding max|fixed factor| of the half-step in progress (split-fp16 copies)
     double n_non_missing = 0.0, kl_const = 0.0;
 
     // factors
@@ -109,7 +111,7 @@ struct nnlm_handle {
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
-    unsigned *maxbits = nullptr; // device [8]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter,
+    unsigned *maxbits = nullptr; // device [8]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter, [6],[7] shard_unpack_kernel (W, H),
                                  // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_wgf.h)
     // What the fast sweep leaves behind for the next half-step (dense one-GPU split-fp16 path): max|x| in maxbits[4 + sg_par] and
     // sg_nslabs Gram partial sums (one per workgroup) in sg_slabs.  sg_which: the factor they describe (1 = H, 0 = W, -1 = none).
@@ -603,6 +605,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
+    h->upk_max_for = -1;
     if (k != h->k) {
         free_factors(h);
         h->k = k;
@@ -1302,14 +1305,14 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
     static int g32 = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "f64") == 0) ? 0 : 1;
     const bool f32rows = use_mfma && !generic_rank(h) && h->prec == NNLM_PREC_F32 && g32;
     // F32 mode with split-fp16 cross products: the Grams on the fp16 matrix cores from the split copy of the rows (na_gram_f16_kernel).
-    // max|fixed factor| is in maxbits[0] (prepare_factor16 ran for this half-step's cross product).  NNLM_NA_GRAM_F16=0: fp32 rows.
+    // max|fixed factor| is in *fixed_maxw (prepare_factor16 ran for this half-step's cross product).  NNLM_NA_GRAM_F16=0: fp32 rows.
     static int f16_env = getenv("NNLM_NA_GRAM_F16") ? atoi(getenv("NNLM_NA_GRAM_F16")) : 1;
     const bool f16rows = f32rows && h->x16 && f16_env;
     if (f16rows) {
         int rc = ensure_na_lists(h, which, bits, words, p, ncols);
         if (rc != NNLM_OK) return rc;
         // [p + 64 rows][64 hi | 64 lo halves]; rows p .. are zero (the kernel's "no row" index)
-        factor16c_kernel<<<p / 64 + 1, 256, 0, h->stream>>>(Ym, ldy, p, h->k, h->maxbits, h->scal_exp + 3, (uint32_t *)h->Yrow);
+        factor16c_kernel<<<p / 64 + 1, 256, 0, h->stream>>>(Ym, ldy, p, h->k, h->fixed_maxw ? h->fixed_maxw : h->maxbits, h->scal_exp + 3, (uint32_t *)h->Yrow);
         const int nb = (nc + 3) / 4;
 #define NNLM_NAGH(N_) na_gram_f16_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const uint32_t *)h->Yrow, p, h->scal_exp + 3, h->Graw, h->Gcols, c1, c0, h->k)
         switch (h->NKQ) {
@@ -1685,7 +1688,13 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HIPCHK(h, hipEventRecord(h->ev_factor, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream_g, h->ev_factor, 0));
     // 1. cross product slabs
-    if (h->x16) prepare_factor16(h, which);
+    if (h->x16) {
+        // (multi-GPU: the unpack of the previous half-step left max|fixed factor| behind -- no absmax pass)
+        const int solved_by = (which == 1) ? 0 : 1; // the half-step that solved this half-step's fixed factor
+        unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : nullptr;
+        prepare_factor16(h, which, mb);
+        h->fixed_maxw = mb ? mb : h->maxbits;
+    }
     if (p.tiles_x > 0) {
         ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
         if (generic_rank(h)) {
@@ -1730,13 +1739,16 @@ static int shard_unpack(nnlm_handle *h, int which)
     const ShardCols sc = shard_cols(h, ncols);
     const size_t tot = (size_t)h->nranks * h->k * sc.cpr; // (the k meaningful rows of every rank's [KP][cpr] slab travel, not the padding)
     const int f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
+    unsigned *maxw = h->x16 ? h->maxbits + 6 + which : nullptr; // max|factor| for the next half-step's split copy (no absmax pass there)
+    if (maxw) HIPCHK(h, hipMemsetAsync(maxw, 0, sizeof(unsigned), h->stream));
+    h->upk_max_for = maxw ? which : -1;
     if (which == 1)
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols, h->H64,
-                                                                                   h->mpad, h->Hop, 2, h->KP, f64);
+                                                                                   h->mpad, h->Hop, 2, h->KP, f64, maxw);
     else
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols,
                                                                                    h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
-                                                                                   f64 ? 0 : 1, h->npad, f64);
+                                                                                   f64 ? 0 : 1, h->npad, f64, maxw);
     HIPCHK(h, hipGetLastError());
     return NNLM_OK;
 }
