@@ -401,8 +401,8 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
             }
 }
 
-// fp32 per-column Gram with the listed rows gathered by LDS-DMA (global_load_lds_dwordx4): a group of four rows is ONE
-// instruction per wavefront (lane = 16-byte chunk: row lane / (KP/4), chunk lane % (KP/4)) that lands in one of four stage buffers
+// Per-column Gram (T = float: fp32-operand mode with NNLM_NA_GRAM_F16=0; T = double: the strict mode) with the listed rows gathered by
+// LDS-DMA (global_load_lds_dwordx4): a group of four rows is ONE instruction per wavefront (two for fp64 rows of 64) (lane = 16-byte chunk: row lane / (KP/4), chunk lane % (KP/4)) that lands in one of four stage buffers
 // of the wavefront and occupies no VGPR.  Three groups are in flight while one is multiplied (s_waitcnt vmcnt(3), written by hand:
 // the instruction is issued as inline asm, so the compiler's wait-count pass neither sees it nor serialises the LDS reads behind
 // it).  Register-destination gathers (na_gram_mfma_kernel) leave the depth of the pipeline to the register
@@ -416,21 +416,26 @@ __global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__res
 // for the lane's NT coordinates q, + the 2 x 2 corner -- 2 NT + 3 fp32 FMAs per four rows, issued under the MFMAs.  A lane sums
 // ITS row of each group of four; the four lane groups are added at the end.  The fp64 images of the tail sums are touched once
 // per 256 rows and live in LDS.  Entries beyond k are never read by the solvers and are not written.
-template <int NT, bool TAIL>
+__device__ static inline float na_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ static inline double na_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T, int NT, bool TAIL>
 __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
-                                                          const float *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
+                                                          const T *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
                                                           int ncols, int col0, int k)
 {
-    using M = Mfma<float>;
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    constexpr bool F32 = sizeof(T) == 4;
     constexpr int KP = 16 * (NT + (TAIL ? 1 : 0));
     constexpr int NP = NT * (NT + 1) / 2;
     constexpr int C0 = 16 * NT, C1 = 16 * NT + 1;
-    constexpr int CH = KP / 4;   // 16-byte chunks per row
-    constexpr int STG = 4;       // stage buffers per wavefront
-    constexpr int SF = 4 * KP;   // floats per stage: four rows
+    constexpr int CH = KP * (int)sizeof(T) / 16;  // 16-byte chunks per row
+    constexpr int NI = (4 * CH + 63) / 64;        // gather instructions per group of four rows (1 for fp32 rows, 2 for fp64 rows of 64)
+    constexpr int STG = 4;                        // stage buffers per wavefront
+    constexpr int SF = 4 * KP;                    // elements per stage: four rows
     constexpr int NTL = TAIL ? 2 * NT + 3 : 1;
-    __shared__ __attribute__((aligned(16))) float stage_all[4][STG][SF];
-    __shared__ double tail64[4][NTL][64];
+    __shared__ __attribute__((aligned(16))) T stage_all[4][STG][SF];
+    __shared__ double tail64[F32 ? 4 : 1][NTL][64]; // (fp32 rows: fp64 images of the tail sums)
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
     const int col = col0 + blockIdx.x * 4 + wave;
     if (col >= ncols) return; // whole wave
@@ -438,17 +443,19 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
     const int ulen = __builtin_amdgcn_readfirstlane((int)(mt & 0x7FFFFFFFu));
     const bool complement = (mt >> 31) != 0;
     const int base = __builtin_amdgcn_readfirstlane((int)ptr[col]);
-    float *stage = &stage_all[wave][0][0];
-    double(*t64)[64] = tail64[wave];
+    T *stage = &stage_all[wave][0][0];
+    double(*t64)[64] = tail64[F32 ? wave : 0];
 
-    f32x4 acc[NP];
-    f64x4 acc64[NP];
-    float ta[NT], tb[NT], tt[3] = {0.f, 0.f, 0.f};
+    acc_t acc[NP];
+    f64x4 acc64[F32 ? NP : 1];
+    T ta[NT], tb[NT], tt[3] = {(T)0, (T)0, (T)0};
 #pragma unroll
-    for (int i = 0; i < NP; i++) acc[i] = f32x4{0, 0, 0, 0}, acc64[i] = f64x4{0, 0, 0, 0};
+    for (int i = 0; i < NP; i++) acc[i] = acc_t{0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < NT; t++) ta[t] = tb[t] = 0.f;
-    if (TAIL) {
+    for (int i = 0; i < (F32 ? NP : 1); i++) acc64[i] = f64x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; t++) ta[t] = tb[t] = (T)0;
+    if (TAIL && F32) {
 #pragma unroll
         for (int e = 0; e < NTL; e++) t64[e][lane] = 0.0;
     }
@@ -457,38 +464,50 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         int a, b, c, d;
     };
     const int ngt = (ulen + 3) >> 2, ng = ulen >> 2; // groups, full groups
-    auto load_idx = [&](int g, Idx4 &ri) {            // (the list array carries 16 words of slack behind its end)
+    auto load_idx = [&](int g, Idx4 &ri) {            // (the list array carries slack behind its end)
         const int *src = idx + base + 4 * g;
         ri.a = src[0], ri.b = src[1], ri.c = src[2], ri.d = src[3];
     };
-    // DMA role of the lane
-    const int drow = lane / CH, dch = lane % CH;
-    const bool dact = lane < 4 * CH;
-    const int m1 = (drow == 1) ? -1 : 0, m2 = (drow == 2) ? -1 : 0, m3 = (drow == 3) ? -1 : 0;
     const unsigned long long yp = (unsigned long long)Yrow;
     const unsigned long long ybase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yp >> 32)) << 32) |
                                      (unsigned)__builtin_amdgcn_readfirstlane((int)yp);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float *)stage);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) T *)stage);
+    // DMA role of the lane in instruction ii: chunk 64 ii + lane = row c / CH, chunk c % CH (loop-invariant lane constants; lane masks,
+    // not a ?: chain over the indices: that becomes a scratch array here)
+    int drow_[NI], m1_[NI], m2_[NI], m3_[NI];
+    unsigned choff_[NI];
+    bool dact_[NI];
+#pragma unroll
+    for (int ii = 0; ii < NI; ii++) {
+        const int c = 64 * ii + lane;
+        drow_[ii] = c / CH;
+        choff_[ii] = (unsigned)(c % CH) * 16u;
+        dact_[ii] = c < 4 * CH;
+        m1_[ii] = (drow_[ii] == 1) ? -1 : 0, m2_[ii] = (drow_[ii] == 2) ? -1 : 0, m3_[ii] = (drow_[ii] == 3) ? -1 : 0;
+    }
     auto issue = [&](int g, const Idx4 &ri) { // group g (wave-uniform) into stage g % STG; rows past the end of the list repeat the group's first
-        int row = ri.a ^ ((ri.a ^ ri.b) & m1) ^ ((ri.a ^ ri.c) & m2) ^ ((ri.a ^ ri.d) & m3);
-        if (4 * g + drow >= ulen) row = ri.a;
-        const unsigned voff = (unsigned)row * (unsigned)(KP * 4) + (unsigned)dch * 16u;
-        const unsigned dst = lds0 + (unsigned)(g & (STG - 1)) * (unsigned)(SF * 4);
-        if (dact) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst) : "memory");
+#pragma unroll
+        for (int ii = 0; ii < NI; ii++) {
+            int row = ri.a ^ ((ri.a ^ ri.b) & m1_[ii]) ^ ((ri.a ^ ri.c) & m2_[ii]) ^ ((ri.a ^ ri.d) & m3_[ii]);
+            if (4 * g + drow_[ii] >= ulen) row = ri.a;
+            const unsigned voff = (unsigned)row * (unsigned)(KP * sizeof(T)) + choff_[ii];
+            const unsigned dst = lds0 + (unsigned)(g & (STG - 1)) * (unsigned)(SF * sizeof(T)) + (unsigned)ii * 1024u;
+            if (dact_[ii]) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst) : "memory");
+        }
     };
     struct Row {
-        float x[NT];
-        float tl[2];
+        T x[NT];
+        T tl[2];
     };
     auto fetch = [&](int g, Row &r) { // operands of group g from its stage buffer
-        const float *sb = stage + (g & (STG - 1)) * SF + lg * KP;
+        const T *sb = stage + (g & (STG - 1)) * SF + lg * KP;
 #pragma unroll
         for (int t = 0; t < NT; t++) r.x[t] = sb[16 * t + l15];
         if (TAIL) {
             r.tl[0] = sb[C0];
             r.tl[1] = sb[C1];
         } else {
-            r.tl[0] = r.tl[1] = 0.f;
+            r.tl[0] = r.tl[1] = (T)0;
         }
     };
     auto mult = [&](const Row &x) {
@@ -500,12 +519,12 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         if (TAIL) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                ta[t] = __builtin_fmaf(x.tl[0], x.x[t], ta[t]);
-                tb[t] = __builtin_fmaf(x.tl[1], x.x[t], tb[t]);
+                ta[t] = na_fma(x.tl[0], x.x[t], ta[t]);
+                tb[t] = na_fma(x.tl[1], x.x[t], tb[t]);
             }
-            tt[0] = __builtin_fmaf(x.tl[0], x.tl[0], tt[0]);
-            tt[1] = __builtin_fmaf(x.tl[0], x.tl[1], tt[1]);
-            tt[2] = __builtin_fmaf(x.tl[1], x.tl[1], tt[2]);
+            tt[0] = na_fma(x.tl[0], x.tl[0], tt[0]);
+            tt[1] = na_fma(x.tl[0], x.tl[1], tt[1]);
+            tt[2] = na_fma(x.tl[1], x.tl[1], tt[2]);
         }
     };
     if (ngt > 0) {
@@ -526,26 +545,27 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
             const int gi = (g + 3 < last) ? g + 3 : last;
             issue(gi, ri);
             load_idx((g + 4 < last) ? g + 4 : last, ri);
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // groups g + 1 .. g + 3 may still be on their way
+            if (NI == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // groups g + 1 .. g + 3 may still be on their way
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             Row x;
             fetch(g, x);
             mult(x);
-            if (++since == 64) { // 256 rows: fp32 partial sums into their fp64 images
+            if (F32 && ++since == 64) { // 256 rows: fp32 partial sums into their fp64 images
                 since = 0;
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) acc64[i][r] += (double)acc[i][r];
-                    acc[i] = f32x4{0, 0, 0, 0};
+                    for (int r = 0; r < 4; r++) acc64[F32 ? i : 0][r] += (double)acc[i][r];
+                    acc[i] = acc_t{0, 0, 0, 0};
                 }
                 if (TAIL) {
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         t64[t][lane] += (double)ta[t], t64[NT + t][lane] += (double)tb[t];
-                        ta[t] = tb[t] = 0.f;
+                        ta[t] = tb[t] = (T)0;
                     }
 #pragma unroll
-                    for (int e = 0; e < 3; e++) t64[2 * NT + e][lane] += (double)tt[e], tt[e] = 0.f;
+                    for (int e = 0; e < 3; e++) t64[2 * NT + e][lane] += (double)tt[e], tt[e] = (T)0;
                 }
             }
         }
@@ -555,8 +575,8 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
             fetch(ng, x);
             if (4 * ng + lg >= ulen) {
 #pragma unroll
-                for (int t = 0; t < NT; t++) x.x[t] = 0.f;
-                x.tl[0] = x.tl[1] = 0.f;
+                for (int t = 0; t < NT; t++) x.x[t] = (T)0;
+                x.tl[0] = x.tl[1] = (T)0;
             }
             mult(x);
         }
@@ -575,7 +595,8 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * a + M::row_of(lane, r), j = 16 * b + l15;
-                const double sum = acc64[pi][r] + (double)acc[pi][r];
+                double sum = (double)acc[pi][r];
+                if (F32) sum += acc64[F32 ? pi : 0][r];
                 const double v = complement ? Gfull[i * KP + j] - sum : sum;
                 if (TAIL || (i < k && j < k)) { // (entries beyond k are never read by the solvers)
                     out[i * KP + j] = v;
@@ -587,7 +608,8 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         // group 1 row C1, lane 32 the corner
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            double va = t64[t][lane] + (double)ta[t], vb = t64[NT + t][lane] + (double)tb[t];
+            double va = (double)ta[t], vb = (double)tb[t];
+            if (F32) va += t64[t][lane], vb += t64[NT + t][lane];
             va += __shfl_xor(va, 16, 64);
             va += __shfl_xor(va, 32, 64);
             vb += __shfl_xor(vb, 16, 64);
@@ -599,7 +621,8 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         double c[3];
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            c[e] = t64[2 * NT + e][lane] + (double)tt[e];
+            c[e] = (double)tt[e];
+            if (F32) c[e] += t64[2 * NT + e][lane];
             c[e] += __shfl_xor(c[e], 16, 64);
             c[e] += __shfl_xor(c[e], 32, 64);
         }

@@ -1341,15 +1341,18 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
         static int tail_env = getenv("NNLM_NA_GRAM_TAIL") ? atoi(getenv("NNLM_NA_GRAM_TAIL")) : 1;
         static int lds_env = getenv("NNLM_NA_GRAM_LDS") ? atoi(getenv("NNLM_NA_GRAM_LDS")) : 1;
         const int ntail = h->k - 16 * (h->NKQ - 1);
-        if (f32rows && lds_env) { // rows gathered by LDS-DMA (k_missing.h, na_gram_lds_kernel); NNLM_NA_GRAM_LDS=0: register gathers
+        if (lds_env) { // rows gathered by LDS-DMA (k_missing.h, na_gram_lds_kernel); NNLM_NA_GRAM_LDS=0: register gathers
             const bool tl = tail_env && h->NKQ >= 2 && (ntail == 1 || ntail == 2);
-#define NNLM_NAGL(N_, T_) na_gram_lds_kernel<N_, T_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const float *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
-            switch (h->NKQ) {
-            case 1: NNLM_NAGL(1, false); break;
-            case 2: if (tl) NNLM_NAGL(1, true); else NNLM_NAGL(2, false); break;
-            case 3: if (tl) NNLM_NAGL(2, true); else NNLM_NAGL(3, false); break;
-            default: if (tl) NNLM_NAGL(3, true); else NNLM_NAGL(4, false); break;
-            }
+#define NNLM_NAGL(T_, N_, TL_) na_gram_lds_kernel<T_, N_, TL_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const T_ *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
+#define NNLM_NAGL_T(T_)                                                           \
+    switch (h->NKQ) {                                                             \
+    case 1: NNLM_NAGL(T_, 1, false); break;                                       \
+    case 2: if (tl) NNLM_NAGL(T_, 1, true); else NNLM_NAGL(T_, 2, false); break;  \
+    case 3: if (tl) NNLM_NAGL(T_, 2, true); else NNLM_NAGL(T_, 3, false); break;  \
+    default: if (tl) NNLM_NAGL(T_, 3, true); else NNLM_NAGL(T_, 4, false); break; \
+    }
+            if (f32rows) { NNLM_NAGL_T(float) } else { NNLM_NAGL_T(double) }
+#undef NNLM_NAGL_T
 #undef NNLM_NAGL
             return NNLM_OK;
         }
