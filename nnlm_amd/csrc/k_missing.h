@@ -885,3 +885,113 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
+
+// colsolve_strict_kernel -- SCD-LS per column in the REFERENCE's arithmetic (strict fp64 mode) with the structure of
+// colsolve_fast_kernel: one wavefront per column, lane = coordinate, row `lane` of the edited Gram in registers, the coordinate loop
+// fully unrolled.  Every lane evaluates the step of ITS coordinate from its own x, mu, G[lane][lane] -- tmp = max(x - mu / G, 0) with
+// the correctly rounded quotient (reciprocal + Markstein correction, k_sweep.h), d = tmp - x -- and lane q's d is the step's delta:
+// 2 v_readlane_b32 + 1 v_fma_f64 bring mu up to date (d = 0 when the reference skips the coordinate: adds nothing).  Lane q keeps
+// tmp itself (x + d is not always tmp) through two v_cndmask_b32 under a literal lane mask.  The rel-change test runs once per sweep
+// on all lanes (a coordinate moves once per sweep: same maximum), division free as in colsolve_ls_kernel.  11 VALU instructions per
+// coordinate against ~15 + a rolled loop with register-indexed Gram reads and eight v_readlane_b32 in colsolve_ls_kernel.
+template <int NKQ, bool HAS_MASK, int KR = 16 * NKQ>
+__global__ __launch_bounds__(256) void colsolve_strict_kernel(const SweepArgs a, size_t g_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const int col = a.col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= a.ncols) return; // whole wavefront
+    const int k = a.k;
+    const bool lv = lane < k;
+    const int lq = lv ? lane : 0;
+    const double *G = a.Graw + (size_t)col * g_stride;
+    unsigned long long mword = 0ull;
+    if (HAS_MASK) mword = a.mask[col];
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const bool skip = HAS_MASK && ((mword & kmask) == kmask); // arma::all(mask.col(j)), src/update_with_missing.cpp:75-76
+
+    double gd = 1.0; // edited G[lane][lane] (src/update_with_missing.cpp:98-103)
+    if (lv) {
+        gd = G[(size_t)lq * a.KPg + lq];
+        if (a.r0 != a.r1) gd += a.r0 - a.r1;
+        if (a.r1 != 0) gd += a.r1;
+        gd += NNLM_TINY;
+    }
+    const double rgd = 1.0 / gd;
+    double g[KR]; // row `lane` of the edited Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
+#pragma unroll
+    for (int q = 0; q < KR; q++) {
+        double v = 0.0;
+        if (q < k && lv) {
+            v = G[(size_t)q * a.KPg + lane];
+            if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
+            if (a.r1 != 0) v += a.r1;
+            if (q == lane) v += NNLM_TINY;
+        }
+        g[q] = v;
+    }
+    double x = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
+    double cv = 0.0;
+    if (lv)
+        for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)lq * a.ldc + col];
+    // mu = G x - c (+ L1), summed in the order of colsolve_ls_kernel
+    double mu = 0.0;
+#pragma unroll
+    for (int q = 0; q < KR; q++)
+        if (q < k) mu = __builtin_fma(g[q], readlane_f64(x, q), mu);
+    mu -= cv;
+    if (a.r2 != 0) mu += a.r2;
+    if (!lv) mu = 0.0;
+
+    unsigned t = 0;
+    if (!skip) {
+        bool more = true; // rel = 1 + rel_tol > rel_tol
+        for (; t < a.max_iter && more; t++) {
+            double xn = x; // the sweep's new coordinates (lane q's changes at step q; x keeps the sweep's start for the test below)
+            int kk = k;
+            asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
+            auto step = [&](const int q) {
+                const double q0 = mu * rgd;
+                const double rr = __builtin_fma(-q0, gd, mu);
+                const double quo = __builtin_fma(rr, rgd, q0); // = mu / G[lane][lane], correctly rounded
+                double tmp;
+                asm("v_max_f64 %0, %1, 0" : "=v"(tmp) : "v"(x - quo)); // tmp = x - mu / G; if (tmp < 0) tmp = 0   (base_algorithms.cpp:23-24)
+                const double dd = tmp - x;
+                int2 dp = __builtin_bit_cast(int2, dd);
+                const int dlo = __builtin_amdgcn_readlane(dp.x, q), dhi = __builtin_amdgcn_readlane(dp.y, q);
+                mu = __builtin_fma(__builtin_bit_cast(double, int2{dlo, dhi}), g[q], mu); // mu += (tmp - x) * G.col(q)     (:26)
+                int2 xp = __builtin_bit_cast(int2, xn), tp = __builtin_bit_cast(int2, tmp);
+                asm volatile("s_mov_b32 vcc_lo, %4\n\ts_mov_b32 vcc_hi, %5\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
+                             : "+v"(xp.x), "+v"(xp.y)
+                             : "v"(tp.x), "v"(tp.y), "n"(q < 32 ? (int)(1u << (q & 31)) : 0), "n"(q >= 32 ? (int)(1u << (q & 31)) : 0)
+                             : "vcc");
+                xn = __builtin_bit_cast(double, xp);
+            };
+#pragma unroll
+            for (int c = 0; c < NKQ; c++) {
+                if (!HAS_MASK && 16 * c + 16 <= KR && 16 * c + 16 <= kk) { // a whole block of 16 coordinates: no per-step test
+#pragma unroll
+                    for (int e = 0; e < 16; e++) step(16 * c + e);
+                } else if (16 * c < kk) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        if (16 * c + e < KR) // (compile time)
+                            if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
+                }
+            }
+            const bool big = 2 * fabs(x - xn) > a.rel_tol * (xn + x + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
+            x = xn;
+            more = __ballot(big && lv) != 0ull || 0.0 > a.rel_tol;
+        }
+    }
+    if (lv) {
+        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = x;
+        if (a.op_mode == 1) {
+            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
+            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
+        } else if (a.op_mode == 2) {
+            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
+            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
+        }
+    }
+    if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
+}

@@ -1239,10 +1239,36 @@ static int sweep_wave_cols_max()
     return v;
 }
 
+template <int NKQ>
+static void launch_colsolve_strict_m(const SweepArgs &a, size_t g_stride, hipStream_t s)
+{
+    const int nb = (a.ncols - a.col0 + 3) / 4;
+    if (nb <= 0) return;
+    constexpr int KS = NKQ > 1 ? 16 * (NKQ - 1) + 4 : 16;
+    if (NKQ > 1 && a.k <= KS) {
+        if (a.mask) colsolve_strict_kernel<NKQ, true, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        else colsolve_strict_kernel<NKQ, false, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        return;
+    }
+    if (a.mask) colsolve_strict_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
+    else colsolve_strict_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
+}
 static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
 {
     if (colsolve_fast_ok(h, method)) {
         launch_colsolve_fast(h, a, g_stride);
+        return;
+    }
+    // SCD in the reference's arithmetic (strict mode, NNLM_COLSOLVE_FAST=0): the unrolled lane-local form; NNLM_COLSOLVE_STRICT=0 keeps
+    // colsolve_ls_kernel (which also runs the Lee updates)
+    static int strict_env = getenv("NNLM_COLSOLVE_STRICT") ? atoi(getenv("NNLM_COLSOLVE_STRICT")) : 1;
+    if (strict_env && method == 1 && h->k <= NNLM_KQ_MAX) {
+        switch (h->NKQ) {
+        case 1: launch_colsolve_strict_m<1>(a, g_stride, h->stream); break;
+        case 2: launch_colsolve_strict_m<2>(a, g_stride, h->stream); break;
+        case 3: launch_colsolve_strict_m<3>(a, g_stride, h->stream); break;
+        default: launch_colsolve_strict_m<4>(a, g_stride, h->stream); break;
+        }
         return;
     }
     switch (h->NKQ) {
