@@ -64,38 +64,23 @@ __device__ static inline long long wave_sum_ll(long long v)
     return v;
 }
 
-#define SWEEP_WG_CONSTS 40 // doubles per block in the constants image of the SCD sweep (k_sweep_wg.h, k_sweep_wgf.h)
-// First coordinate of the "tail block" of k_sweep_wgf.h -- k = 16 j + 1 or + 2, j >= 1: the one or two coordinates beyond a
-// multiple of 16 are carried by the chain wave and the update waves hold 16 j instead of 16 (j + 1) -- or -1.
-__host__ __device__ static inline int sweep_tail_coord(int k) { return (k > 16 && (k % 16 == 1 || k % 16 == 2)) ? (k / 16) * 16 : -1; }
+#define SWEEP_WG_CONSTS 32 // doubles per block in the constants image of the strict SCD sweep (k_sweep_wg.h)
 
 // One entry of the constants image the chain wave of sweep_scd_wg_kernel reads (layout: k_sweep_wg.h); shared by
 // sweep_consts_kernel and gram_reduce_consts_kernel.
-// FAST (fp32-operand mode): every row of G is divided by its diagonal, so the update waves carry nu = mu / G[q][q] and
-// the chain wave needs no quotient: [8..13] and [16..31] hold the scaled entries, [0..3] stay 1 / G[q][q] (the sweep
-// kernel scales its own image of G and the initial gradient with them).
-template <class F> __device__ static inline double sweep_wg_const(F edited, int k, int nbk, int b, int i, int fast)
+template <class F> __device__ static inline double sweep_wg_const(F edited, int k, int nbk, int b, int i)
 {
     const int nb = (b + 1 < nbk) ? b + 1 : 0;
     if (i < 4) return 1.0 / edited(4 * b + i, 4 * b + i);
     if (i < 8) return edited(4 * b + i - 4, 4 * b + i - 4);
     if (i < 14) {
         const int s2[6] = {1, 2, 2, 3, 3, 3}, s[6] = {0, 0, 1, 0, 1, 2};
-        const int r = 4 * b + s2[i - 8];
-        const double v = edited(r, 4 * b + s[i - 8]);
-        return fast ? v * (1.0 / edited(r, r)) : v;
+        return edited(4 * b + s2[i - 8], 4 * b + s[i - 8]);
     }
     if (i >= 16 && i < 32) {
         const int ss = (i - 16) / 4, g = (i - 16) % 4, r = 4 * nb + ss;
         if (!(r < k && 4 * b + g < k)) return 0.0;
-        const double v = edited(r, 4 * b + g);
-        return fast ? v * (1.0 / edited(r, r)) : v;
-    }
-    if (i >= 32 && fast) { // [32..39]: scaled rows of the two tail coordinates, columns of block b (k_sweep_wgf.h, TAIL)
-        const int tc = sweep_tail_coord(k), r = tc + (i - 32) / 4, kc = 4 * b + (i - 32) % 4;
-        if (tc < 0 || !(r < k && kc < k)) return 0.0;
-        return edited(r, kc) * (1.0 / edited(r, r));
+        return edited(r, 4 * b + g);
     }
     return 0.0;
 }
-

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restr
     }
 }
 
-// G = sum of MANY slabs (one per workgroup of the fast sweep kernel, k_sweep_wgf.h: hundreds), no fences, fixed order:
+// G = sum of MANY slabs (one per workgroup of the fast sweep kernel, k_sweep_q.h: hundreds), no fences, fixed order:
 // a block owns 64 consecutive entries, its 16 wavefronts add every 16th slab (coalesced 512-byte reads), LDS folds the
 // 16 partial sums in index order.  Launch with KP*KP/64 blocks of 1024 threads.  Lower tiles are written as mirrors.
 __device__ static inline void gram_fold_body(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G, int blk)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
 // (device counter, reset for the next launch) has all of G in front of it and writes the constants image.
 __global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
                                                                  int k, double r0, double r1, double *__restrict__ consts,
-                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word, int fast)
+                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word)
 {
     __shared__ double part[4][64];
     __shared__ int last_s;
@@ -229,5 +229,5 @@ __global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *_
         if (c == kc) v += NNLM_TINY;
         return v;
     };
-    for (int t = threadIdx.x; t < nbk * SWEEP_WG_CONSTS; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / SWEEP_WG_CONSTS, t % SWEEP_WG_CONSTS, fast);
+    for (int t = threadIdx.x; t < nbk * SWEEP_WG_CONSTS; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / SWEEP_WG_CONSTS, t % SWEEP_WG_CONSTS);
 }

@@ -1,0 +1,362 @@
+// k_sweep_q.h -- SCD least-squares sweep of the fp32-operand mode, ONE wavefront per 16 columns, no exchange between
+// wavefronts at all: the whole recurrence of scd_ls_update (reference src/base_algorithms.cpp:3-37) on
+// v_mfma_f64_4x4x4_4b_f64.
+//
+// What the workgroup-specialised kernel (k_sweep_wgf.h) paid per block of 4 coordinates -- one s_barrier and two LDS round
+// trips per role, ~500 of its ~690 cycles -- came from the operand layouts: the chain wanted
+// lane = column, the 16x16x4 matrix instruction wants lane = (coordinate, column).  The 4x4x4 instruction with 4 blocks
+// (probed on the box, scripts/exp/mfma44_exp.hip: A lane = 16 k + 4 blk + i, B lane = 16 k + 4 blk + j,
+// D lane = 16 i + 4 blk + j; 16.6 cycles back to back; cbsz / abid are ignored, scripts/exp/mfma44_cbsz.hip) has the SAME
+// lane map for its B operand and its result: lane (i, col) with col = 4 blk + j.  So with
+//      block beta = coordinates 4 beta .. 4 beta + 3,   accumulator acc[beta] at lane (i, col) = nu[4 beta + i][col]
+// (nu = mu / G[q][q], rows of G divided by their diagonal as in k_sweep_wgf.h) the deltas of a block, computed by the lanes
+// that hold its gradients, ARE the B operand of the rank-4 update of every other block -- nothing moves between lanes.
+//   * The four dependent coordinate steps of a block run on the matrix core as well: with L = the strictly lower part of the
+//     block's own 4x4 piece of G',   c <- max(-x, -(m0 + L c))   three times makes rows 0..s of c final after pass s
+//     (row s only needs rows < s), so after three passes c is the block's delta vector: 4 v_max_f64 + 3 small MFMAs, no
+//     cross-lane traffic, no per-coordinate FMAs.  Candidates of rows that are not final yet are finite and multiplied by zeros.
+//   * A operands: lane (k, blk, i) of an operand holds G'[4 b + i][4 beta + k] (the same 16 numbers in all four blk groups;
+//     the instruction cannot broadcast them).  All NB (NB + 1) operands are 364 registers at k = 50 -- too many next to a
+//     second wavefront on the SIMD -- so they live in an LDS image (23 KB) and a step fetches the NB + 1 it needs with
+//     ds_read_b128 (two operands each) one step ahead; the operands of a block are used by its urgent product and by the
+//     next step's lazy products, so two register sets alternate.
+//   * Per step: 3 chain + NB - 1 lazy + 1 urgent MFMAs (the next block's accumulator) and 5 VALU instructions (+ 3 while the
+//     rel-change tests are on); the lazy products of the previous block's deltas fill the issue slots between the dependent
+//     chain instructions.  No barrier, no scalar loads inside the sweep.
+//   * Columns that are done (rel_err <= rel_tol) are written to the x image in LDS at that moment and keep being computed
+//     (their lanes cost nothing); masked coordinates carry x = 0, nu = 1e300 in the loop (delta = -0) and take their value
+//     from the input when a column is written.
+// Same arithmetic as k_sweep_wgf.h up to the order in which a block's four deltas are added to a gradient (the matrix
+// core's); the epilogue (factor outputs, max|x|, Gram partial sums for the next half-step) is that kernel's.
+#pragma once
+#include "common.h"
+#include "k_sweep.h"
+#include <type_traits>
+
+#define SWEEPQ_THREADS 256
+#define SWEEPQ_COLS 64 // columns per workgroup, 16 per wavefront
+
+__host__ __device__ static inline int sweepq_np(int NB) { return (NB + 2) / 2; }                         // operand PAIRS per step
+__host__ __device__ static inline size_t sweepq_img_doubles(int NB) { return (size_t)NB * sweepq_np(NB) * 32 + 4 * NB; }
+
+// Operand image, exactly as the kernel keeps it in LDS: img[((beta * NP + p) * 16 + li) * 2 + e], li = 4 kA + iA, entry s = 2 p + e:
+//   s < NB  : G'[4 s + iA][4 beta + kA]                       (operand of accumulator s for the deltas of block beta)
+//   s == NB : strictly lower part of G'[4 bn + iA][4 bn + kA], bn = (beta + 1) % NB   (chain operand of the NEXT block)
+// followed by rinv[q] = 1 / G[q][q], q < 4 NB.  G' = edited G (src/update_with_missing.cpp:20-24) with row r divided by its
+// diagonal (diagonal exactly 1); coordinates >= k are inert (identity).
+__global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1, int NB,
+                                                          double *__restrict__ img)
+{
+    const int NP = sweepq_np(NB);
+    auto edited = [&](int c, int kc) -> double {
+        if (c >= k || kc >= k) return (c == kc) ? 1.0 : 0.0;
+        double g = Graw[(size_t)c * KPg + kc];
+        if (c == kc && r0 != r1) g += r0 - r1;
+        if (r1 != 0) g += r1;
+        if (c == kc) g += NNLM_TINY;
+        return g;
+    };
+    auto scaled = [&](int r, int c) -> double { return (r == c) ? 1.0 : edited(r, c) * (1.0 / edited(r, r)); };
+    const int total = NB * NP * 32;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total + 4 * NB; e += gridDim.x * 256) {
+        if (e >= total) {
+            img[e] = 1.0 / edited(e - total, e - total);
+            continue;
+        }
+        const int s = 2 * ((e >> 5) % NP) + (e & 1), beta = (e >> 5) / NP, li = (e >> 1) & 15, kA = li >> 2, iA = li & 3;
+        double v = 0.0;
+        if (s < NB) v = scaled(4 * s + iA, 4 * beta + kA);
+        else if (s == NB) {
+            const int bn = (beta + 1) % NB;
+            v = (iA > kA) ? scaled(4 * bn + iA, 4 * bn + kA) : 0.0;
+        }
+        img[e] = v;
+    }
+}
+
+template <int I, int N, class F> __device__ __forceinline__ void sq_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sq_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ double sq_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double sq_delta(double x, double m)
+{
+    double d; // max(x - m, 0) - x = max(-x, -m): one instruction (fmax() costs a canonicalisation and a negation)
+    asm volatile("v_max_f64 %0, -%1, -%2" : "=v"(d) : "v"(x), "v"(m));
+    return d;
+}
+template <int N> __device__ __forceinline__ void sq_nop()
+{
+    if constexpr (N > 0) asm volatile("s_nop %0" ::"n"(N - 1)); // N wait states
+}
+
+// The NL = NB - 1 lazy products of a step, dealt to its four stages: post[s] behind the stage's dependent MFMA (two cover the six
+// wait states the next v_max needs), pre[s] between the v_max and that MFMA (one covers its two); off[] = first product of each slot.
+struct SqSched {
+    int pre[4], post[4], off[8];
+};
+constexpr SqSched sq_sched(int NL)
+{
+    SqSched s{};
+    int left = NL;
+    for (int i = 0; i < 4; i++) {
+        s.post[i] = left < 2 ? left : 2;
+        left -= s.post[i];
+    }
+    for (int i = 0; i < 4; i++) {
+        s.pre[i] = left < 1 ? left : 1;
+        left -= s.pre[i];
+    }
+    for (int i = 0; left > 0; i++, left--) s.post[i % 4]++;
+    int o = 0;
+    for (int i = 0; i < 4; i++) { // slot order pre[0] post[0] pre[1] ...: product 0 (the next block's accumulator) comes first
+        s.off[2 * i] = o;
+        o += s.pre[i];
+        s.off[2 * i + 1] = o;
+        o += s.post[i];
+    }
+    return s;
+}
+
+// NT: the caller's rank padding KP = 16 NT (layout of the outputs and of the Gram slabs); NB = ceil(k / 4) blocks
+template <int NT, int NB, bool HAS_MASK>
+__global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
+{
+    constexpr int KP = 16 * NT, NP = (NB + 2) / 2, XS = KP + 2;
+    static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 3, "NB = ceil(k / 4)");
+    __shared__ __attribute__((aligned(16))) double xl[SWEEPQ_COLS * XS]; // x[column][coordinate], final values
+    __shared__ __attribute__((aligned(16))) double opl[NB * NP * 32];    // the operand image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ri = lane >> 4, c16 = lane & 15; // row of the lane's coordinates inside their blocks; column inside the wavefront
+    const int k = a.k;
+    const int col_base = a.col0 + blockIdx.x * SWEEPQ_COLS;
+    const int cl = 16 * wave + c16, col = col_base + cl;
+    const bool in_range = col < a.ncols;
+    const int cc = in_range ? col : a.col0;
+
+    for (int e = tid; e < NB * NP * 16; e += SWEEPQ_THREADS) ((f64x2 *)opl)[e] = ((const f64x2 *)img)[e];
+    const double *rinv = img + (size_t)NB * NP * 32;
+    unsigned long long mword = 0ull;
+    if (HAS_MASK) mword = a.mask[cc];
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    bool act = in_range && !(HAS_MASK && ((mword & kmask) == kmask)); // arma::all(mask.col(j)) -> column skipped
+    double acc[NB], x[NB];
+    // nu = ((L1 - c) + G x) / diag   (src/update_with_missing.cpp:39-41)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int q = 4 * b + ri;
+        double cv = 0.0, xv = 0.0;
+        if (q < k) {
+            for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)q * a.ldc + cc];
+            xv = in_range ? a.X[(size_t)q * a.ldx + col] : 0.0;
+        }
+        acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) * rinv[q] : 0.0;
+        x[b] = xv;
+    }
+    __syncthreads(); // operand image complete
+    // this lane's operand values: lane (kA, blk, iA) reads entry li = 4 kA + iA of every operand (all four blk groups the same)
+    const f64x2 *opv = (const f64x2 *)opl + (4 * (lane >> 4) + (lane & 3));
+    // pairs p = 0 .. NP - 1 of block B: entries 2 p, 2 p + 1 of fetch(B) -> set[2 p], set[2 p + 1]
+    auto fetch = [&](auto bc, double(&set)[2 * NP]) {
+        constexpr int B = decltype(bc)::value;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const f64x2 v = opv[(B * NP + p) * 16];
+            set[2 * p] = v[0];
+            set[2 * p + 1] = v[1];
+        }
+    };
+    double As[2][2 * NP]; // operand sets by block parity: As[B & 1][s], s < NB: accumulator s <- deltas of block B; [NB]: chain operand of block B + 1
+    sq_for<0, NB>([&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        fetch(bc, As[0]);
+#pragma unroll
+        for (int T = 0; T < NB; T++) acc[T] = sq_mfma(As[0][T], x[B], acc[T]);
+    });
+    if (HAS_MASK) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+            if ((mword >> (4 * b + ri)) & 1ull) x[b] = 0.0, acc[b] = 1e300; // delta = max(-0, -1e300) = -0 for good
+    }
+#ifdef SWEEPQ_DEBUG
+    if (a.op_mode == 99 && blockIdx.x == 0 && wave == 0) { // harness: the initial (scaled) gradients
+#pragma unroll
+        for (int b = 0; b < NB; b++) ((double *)a.op)[(4 * b + ri) * 16 + c16] = acc[b];
+    }
+#endif
+    // the column's final values -> x image (masked entries from the input; rows of out-of-range columns zero)
+    auto write_col = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int q = 4 * b + ri;
+            double v = x[b];
+            if (HAS_MASK && in_range && q < k && ((mword >> q) & 1ull)) v = a.X[(size_t)q * a.ldx + col];
+            xl[cl * XS + q] = in_range ? v : 0.0;
+        }
+    };
+    if constexpr (KP > 4 * NB) { // coordinates beyond the last block
+        constexpr int REST = KP - 4 * NB;
+        for (int e = tid; e < SWEEPQ_COLS * REST; e += SWEEPQ_THREADS) xl[(e / REST) * XS + 4 * NB + e % REST] = 0.0;
+    }
+    if (!act) write_col();
+
+    const double tol = a.rel_tol, tolh = 0.5 * tol, tolhe = 0.5 * tol * NNLM_TINY;
+    unsigned t = 0;
+    int t_lane = 0;
+    bool go = a.max_iter > 0 && __any(act);
+    double d_pend = 0.0; // deltas of the previous block, still owed to every accumulator but the current block's
+    bool flag = false;
+    // entering step 0: As[1] = operands of block NB - 1 (lazy products of d_pend = 0: any finite values), Lc = chain operand of block 0
+    fetch(std::integral_constant<int, NB - 1>{}, As[1]);
+    double Lc = As[1][NB];
+    sq_nop<8>(); // (the initial gradients come out of MFMAs; the first v_max below is inline asm)
+
+    // One block.  The step is four stages  [v_max]  pre  [dependent MFMA]  post : three chain passes and the urgent product.
+    // `pre` / `post` are lazy products of the PREVIOUS block's deltas (independent of the chain): they fill the issue slots the
+    // dependent instructions would otherwise wait through.  The v_max is inline asm, which the compiler's hazard recogniser
+    // does not look into, so the wait states are provided here: a VALU result needs 2 wait states before a DGEMM reads it
+    // (one 4-pass MFMA in between = 4), a 4x4x4 DGEMM result 6 before a VALU reads it (two MFMAs = 8); where a block count
+    // leaves a slot without lazy products, s_nop stands in.  (Found the hard way: without them v_max reads the accumulator's
+    // OLD value -- every x doubled per sweep.)  The scheduling barriers pin the order.
+    auto step = [&](auto bc, auto tc) {
+        constexpr int B = decltype(bc)::value, BN = (B + 1) % NB;
+        constexpr bool TEST = decltype(tc)::value;
+        constexpr SqSched S = sq_sched(NB - 1);
+        double(&Ap)[2 * NP] = As[(B + 1) & 1]; // operands of the previous block (lazy products)
+        double(&Ac)[2 * NP] = As[B & 1];       // operands of this block: fetched now, first used by the urgent product
+        const double m0 = acc[B], xb = x[B];
+        auto lazies = [&](auto fromc, auto toc) { // lazy products number from .. to - 1, the next block's accumulator first
+            sq_for<decltype(fromc)::value, decltype(toc)::value>([&](auto oc) {
+                constexpr int T = (B + 1 + decltype(oc)::value) % NB;
+                acc[T] = sq_mfma(Ap[T], d_pend, acc[T]);
+            });
+        };
+#define SQ_IC(v) std::integral_constant<int, (v)> {}
+#define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    c = sq_delta(xb, val_in);                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
+    lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    dep_expr;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
+    sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+        double c, m;
+        SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))
+#ifndef SWEEPQ_ABL_NOFETCH // (harness ablation: timing without the operand fetches)
+        fetch(bc, Ac); // (the previous step's lazy products were the last readers of this set)
+#endif
+        SQ_STAGE(1, m, m = sq_mfma(Lc, c, m0))
+        SQ_STAGE(2, m, m = sq_mfma(Lc, c, m0))
+        // the fourth stage's dependent product is the urgent one: the next block's gradient (its lazy product came first above)
+        SQ_STAGE(3, m, acc[BN] = sq_mfma(Ac[BN], c, acc[BN]))
+#undef SQ_STAGE
+#undef SQ_IC
+        const double d = c;
+        // rel-change test (src/base_algorithms.cpp:29-32), division-free: 2|d| > tol (x + d + x + eps)
+        if (TEST) flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
+        x[B] = xb + d;
+#ifdef SWEEPQ_DEBUG
+        if (a.op_mode == 99 && t == 0 && blockIdx.x == 0 && wave == 0) {
+            double *dbg = (double *)a.op + 1024 + B * 6 * 64;
+            dbg[lane] = xb, dbg[64 + lane] = m0, dbg[128 + lane] = m, dbg[192 + lane] = d, dbg[256 + lane] = x[B], dbg[320 + lane] = d_pend;
+        }
+#endif
+        d_pend = d;
+        Lc = Ac[NB];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // some live column of the wavefront has no coordinate yet that moved by more than rel_tol
+    auto tests_needed = [&]() -> bool {
+        const unsigned long long bal = __ballot(flag);
+        const unsigned cf = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+        return __any(act && !((cf >> c16) & 1u));
+    };
+    while (go) {
+        flag = 0.0 > tol; // rel_err starts each sweep at 0: a negative rel_tol never stops
+        step(std::integral_constant<int, 0>{}, std::true_type{});
+        if (tests_needed()) {
+            sq_for<1, NB>([&](auto bc) { step(bc, std::true_type{}); });
+        } else {
+            sq_for<1, NB>([&](auto bc) { step(bc, std::false_type{}); });
+        }
+        if constexpr (NB & 1) { // the last block's operands sit in set 0; step 0 reads its lazy operands from set 1
+#pragma unroll
+            for (int s = 0; s < 2 * NP; s++) As[1][s] = As[0][s];
+        }
+        // end of a sweep (src/base_algorithms.cpp:35: stop when rel_err <= rel_tol)
+        const unsigned long long bal = __ballot(flag);
+        const unsigned cf = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+        if (act) {
+            t_lane++;
+            if (!((cf >> c16) & 1u)) {
+                write_col(); // done: these are the column's final values, whatever its lanes go on computing
+                act = false;
+            }
+        }
+        t++;
+        go = t < a.max_iter && __any(act);
+    }
+    if (act) write_col();
+    __syncthreads(); // x image final
+
+    float xmax = 0.0f;
+    for (int e = tid; e < SWEEPQ_COLS * KP; e += SWEEPQ_THREADS) {
+        const int q = e / SWEEPQ_COLS, c = e % SWEEPQ_COLS, ecol = col_base + c;
+        if (q < k && ecol < a.ncols) {
+            const double xv = xl[c * XS + q];
+            xmax = fmaxf(xmax, fabsf((float)xv));
+            a.Xout[(size_t)q * a.ldo + (ecol - a.ocol0)] = xv;
+            if (a.op_mode == 1) {
+                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + ecol] = xv;
+                else ((float *)a.op)[(size_t)q * a.op_ld + ecol] = (float)xv;
+            }
+        }
+    }
+    if (a.op_mode == 2) { // [col][op_ld], kq fastest: consecutive threads write consecutive kq of one column
+        for (int e = tid; e < SWEEPQ_COLS * KP; e += SWEEPQ_THREADS) {
+            const int c = e / KP, q = e % KP, ecol = col_base + c;
+            if (q < k && ecol < a.ncols) {
+                const double xv = xl[c * XS + q];
+                if (a.op_f64) ((double *)a.op)[(size_t)ecol * a.op_ld + q] = xv;
+                else ((float *)a.op)[(size_t)ecol * a.op_ld + q] = (float)xv;
+            }
+        }
+    }
+    if (a.maxbits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
+    }
+    if (a.gram_slabs) {
+        // Gram partial sums of this workgroup's columns, X X^T over the 64 columns with v_mfma_f64_16x16x4_f64, upper tiles dealt
+        // to the four wavefronts, slab layout of gram_partial_kernel (k_gram.h); folded by factor16_fold_kernel (fence-free)
+        const int l15 = lane & 15, lg = lane >> 4;
+        double *slab = a.gram_slabs + (size_t)blockIdx.x * KP * KP;
+        int tix = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+            for (int tb = ta; tb < NT; tb++) {
+                if ((tix++ & 3) != wave) continue;
+                f64x4 g = f64x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < SWEEPQ_COLS / 4; s4++) {
+                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = g[r];
+            }
+    }
+    {
+        const long long tot = wave_sum_ll((ri == 0) ? (long long)t_lane : 0ll);
+        if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
+    }
+}

@@ -1,26 +1,23 @@
 // k_sweep_wg.h -- SCD least-squares sweep, workgroup-specialised: one "chain" wavefront + four "update" wavefronts.
 //
 // Same iteration as scd_ls_update (reference src/base_algorithms.cpp:3-37): coordinates strictly in order 0..k-1, each
-// step sees every earlier update.  sweep_scd_mfma_kernel (k_sweep_mfma.h) runs the whole recurrence of 16 columns in
-// ONE wavefront and is bound by that wavefront's instruction issue (fp64 VALU issues every 8 cycles, the fp64 MFMA is not
-// overlapped by the same wave's VALU work): ~1290 cycles per block of 4 coordinates, of which only the short dependent
-// chain is inherently serial.  Here the work of a block is split by ROLE across the wavefronts of a workgroup that
-// owns 64 columns, synchronised by one s_barrier per block:
+// step sees every earlier update -- in the REFERENCE'S arithmetic (reciprocal + Markstein-corrected quotient = the correctly
+// rounded mu / G[q][q], max, delta): the SCD sweep of the strict fp64 mode and of ranks below 9.  (The fp32-operand mode runs
+// k_sweep_q.h: one wavefront per 16 columns, rows of G divided by their diagonal.)  The work of a block of 4 coordinates is
+// split by ROLE across the wavefronts of a workgroup that owns 48 columns, synchronised by one s_barrier per block:
 //
-//   chain wave (1):  lane = column.  Per block b: m = far[b] + near, the 4 dependent coordinate steps (exactly the
-//     arithmetic of k_sweep_mfma.h: reciprocal + Markstein quotient, max, delta), x_new, the rel-change tests, then
-//     `near` = G[next block, b] * d_b (16 FMAs) -- the one part of the gradient update the NEXT block cannot wait for.
-//     Block constants are wave-uniform and come through the scalar cache (s_load from a small image written by
+//   chain wave (1):  lane = column.  Per block b: m = far[b] + near, the 4 dependent coordinate steps, x_new, the rel-change
+//     tests, then `near` = G[next block, b] * d_b (16 FMAs) -- the one part of the gradient update the NEXT block cannot wait
+//     for.  Block constants are wave-uniform and come through the scalar cache (s_load from a small image written by
 //     sweep_consts_kernel) -- no LDS traffic, no VGPRs.  x lives in LDS ([column][coordinate], padded rows).
-//   update waves (4, 16 columns each):  hold the gradient mu of ALL coordinates in fp64 MFMA accumulators
-//     (v_mfma_f64_16x16x4_f64, the layout of k_sweep_mfma.h).  During block b they apply the deltas of block b-1,
-//     mu += G[:, b-1] * d_{b-1}, and publish `far` = mu[block b+1] -- which therefore holds every update except
-//     d_b, the one the chain wave adds itself as `near`.  They have a whole block time of slack.
+//   update waves (3, 16 columns each):  hold the gradient mu of ALL coordinates in fp64 MFMA accumulators
+//     (v_mfma_f64_16x16x4_f64: coordinate 16 t + 4 r + lg in register r of tile t, lane (lg, column)).  During block b they apply
+//     the deltas of block b-1, mu += G[:, b-1] * d_{b-1}, and publish `far` = mu[block b+1] -- which therefore holds every
+//     update except d_b, the one the chain wave adds itself as `near`.  They have a whole block time of slack.
 //
 // Exchange through LDS, double-buffered by step parity: dbuf (deltas, chain -> update), fbuf (far, update -> chain).
-// The update waves stop being on the critical path; the chain wave does no MFMA, no all-gather and no
-// register-indexed moves.  Differences from the reference's arithmetic stay sub-ulp: a coordinate's gradient is
-// assembled as far + near instead of one running sum (and far accumulates in the matrix core's order).
+// Differences from the reference's arithmetic stay sub-ulp: a coordinate's gradient is assembled as far + near instead of
+// one running sum (and far accumulates in the matrix core's order).
 #pragma once
 #include "common.h"
 #include "k_sweep.h"
@@ -60,7 +57,7 @@ __host__ __device__ static inline int sweep_wg_lds_bytes(int NT)
 // with the regularisation edits of src/update_with_missing.cpp:20-24; padded coordinates: diagonal 1, rest 0.
 // (records are produced by sweep_wg_const, common.h -- shared with gram_reduce_consts_kernel)
 __global__ __launch_bounds__(256) void sweep_consts_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1,
-                                                           double *__restrict__ consts, int fast)
+                                                           double *__restrict__ consts)
 {
     const int nbk = (k + 3) / 4;
     auto edited = [&](int c, int kc) -> double {
@@ -72,7 +69,7 @@ __global__ __launch_bounds__(256) void sweep_consts_kernel(const double *__restr
         return g;
     };
     for (int e = threadIdx.x; e < nbk * SWEEP_WG_CONSTS; e += blockDim.x)
-        consts[e] = sweep_wg_const(edited, k, nbk, e / SWEEP_WG_CONSTS, e % SWEEP_WG_CONSTS, fast);
+        consts[e] = sweep_wg_const(edited, k, nbk, e / SWEEP_WG_CONSTS, e % SWEEP_WG_CONSTS);
 }
 
 template <int NT, bool HAS_MASK>

@@ -18,9 +18,8 @@
 #include "k_missing.h"
 #include "k_prep.h"
 #include "k_sweep.h"
-#include "k_sweep_mfma.h"
 #include "k_sweep_wg.h"
-#include "k_sweep_wgf.h"
+#include "k_sweep_q.h"
 #include "k_xprod.h"
 #include "k_xprod16.h"
 
@@ -108,11 +107,12 @@ struct nnlm_handle {
     double *pack_all = nullptr;  // [nranks][KP][cpr]
     size_t pack_elems = 0;
     double *sweep_consts = nullptr;           // [16][SWEEP_WG_CONSTS] block constants of the chain wave (k_sweep_wg.h)
+    double *sweepq_img = nullptr;             // operand image of sweep_scd_q_kernel (k_sweep_q.h), rewritten every half-step
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
     unsigned *maxbits = nullptr; // device [8]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter, [6],[7] shard_unpack_kernel (W, H),
-                                 // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_wgf.h)
+                                 // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_q.h)
     // What the fast sweep leaves behind for the next half-step (dense one-GPU split-fp16 path): max|x| in maxbits[4 + sg_par] and
     // sg_nslabs Gram partial sums (one per workgroup) in sg_slabs.  sg_which: the factor they describe (1 = H, 0 = W, -1 = none).
     int sg_which = -1, sg_par = 0, sg_nslabs = 0;
@@ -122,6 +122,7 @@ struct nnlm_handle {
     double *sg_slabs = nullptr;
     int mb_par = 0;
     bool consts_ready = false;   // sweep_consts image already produced for this half-step (gram_reduce_consts_kernel)
+    bool pack_ready = false;     // sweepq_img already produced for this half-step (the one-stream dense flow packs it ahead of the cross product)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
     float *What = nullptr;       // [mpad][npad] fp32 W^T H: starting state vectors of a KL half-step (wh_store_kernel), on first use
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
@@ -293,6 +294,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
+        hipMalloc(&h->sweepq_img, sweepq_img_doubles(16) * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->maxbits, 8 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
@@ -395,6 +397,7 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipHostFree(h->host_res);
     hipFree(h->sweeps_tmp);
     hipFree(h->sweep_consts);
+    hipFree(h->sweepq_img);
     hipFree(h->maxbits);
     hipFree(h->scal_exp);
     if (h->ev_factor) hipEventDestroy(h->ev_factor);
@@ -973,74 +976,55 @@ static void launch_sweep_l(int idx, int method, const SweepArgs &a, hipStream_t 
 // Lanes per column.  The sweep is bound by the per-wavefront issue rate (fp64 VALU: one instruction per 8 cycles per
 // wave, measured), so fewer FMAs per lane (larger L) wins as long as the SIMDs are not oversubscribed: L = 4 up to
 // 4 wavefronts per SIMD (measured at config 2: L=4 0.56 ms, L=2 0.85 ms, L=1 1.5 ms per half-step).
-// NNLM_SWEEP_L overrides it for experiments.
 static int sweep_lanes_per_column(int ncols)
 {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("NNLM_SWEEP_L");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
     const long slots = 1024L * 4; // SIMDs x wavefronts per SIMD
     if (((long)ncols * 4 + 63) / 64 <= slots) return 4;
     if (((long)ncols * 2 + 63) / 64 <= slots) return 2;
     return 1;
 }
 
-// SCD-LS on the matrix cores (k_sweep_mfma.h); NNLM_SWEEP_MFMA=0 falls back to the VALU kernel for A/B runs.
-static bool use_mfma_sweep()
+// SCD-LS of the fp32-operand mode: sweep_scd_q_kernel (k_sweep_q.h: one wavefront per 16 columns, the whole recurrence on the
+// 4x4x4 fp64 matrix instruction, rows of G divided by their diagonal).  The strict fp64 mode keeps the reference's arithmetic
+// (correctly rounded mu / G[q][q]) in the workgroup-specialised kernel (k_sweep_wg.h), which also takes ranks below 9 (the
+// one-wavefront kernel needs three blocks of 4 coordinates).
+static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k > 8 && h->k <= NNLM_KQ_MAX; }
+
+template <int NT, int NB> static void launch_sweep_q_m(nnlm_handle *h, const SweepArgs &a, int nb)
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NNLM_SWEEP_MFMA");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+    if (a.mask) sweep_scd_q_kernel<NT, NB, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+    else sweep_scd_q_kernel<NT, NB, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+}
+static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
+{
+    const int nb = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS, NB = (a.k + 3) / 4;
+    if (nb <= 0) return;
+    if (!h->pack_ready) sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img);
+    h->pack_ready = false;
+    switch (NB) {
+    case 3: launch_sweep_q_m<1, 3>(h, a, nb); break;
+    case 4: launch_sweep_q_m<1, 4>(h, a, nb); break;
+    case 5: launch_sweep_q_m<2, 5>(h, a, nb); break;
+    case 6: launch_sweep_q_m<2, 6>(h, a, nb); break;
+    case 7: launch_sweep_q_m<2, 7>(h, a, nb); break;
+    case 8: launch_sweep_q_m<2, 8>(h, a, nb); break;
+    case 9: launch_sweep_q_m<3, 9>(h, a, nb); break;
+    case 10: launch_sweep_q_m<3, 10>(h, a, nb); break;
+    case 11: launch_sweep_q_m<3, 11>(h, a, nb); break;
+    case 12: launch_sweep_q_m<3, 12>(h, a, nb); break;
+    case 13: launch_sweep_q_m<4, 13>(h, a, nb); break;
+    case 14: launch_sweep_q_m<4, 14>(h, a, nb); break;
+    case 15: launch_sweep_q_m<4, 15>(h, a, nb); break;
+    default: launch_sweep_q_m<4, 16>(h, a, nb); break;
     }
-    return v == 1;
 }
 
-// SCD-LS, workgroup-specialised (k_sweep_wg.h: chain wave + update waves); NNLM_SWEEP_WG=0 keeps the one-wave kernel.
-static bool use_wg_sweep()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NNLM_SWEEP_WG");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v == 1;
-}
-
-// The restructured sweep (k_sweep_wgf.h: rows of G divided by their diagonal, quotient-free chain, x kept by the update
-// waves) belongs to the fp32-operand mode; the strict fp64 mode keeps k_sweep_wg.h and the reference's arithmetic
-// (correctly rounded mu / G[q][q]).  NNLM_SWEEP_FAST=0 for A/B runs.
-static bool sweep_fast(const nnlm_handle *h)
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NNLM_SWEEP_FAST");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return h->prec == NNLM_PREC_F32 && v == 1 && h->k > 8; // (x kept by the update waves needs >= 3 blocks of 4 coordinates)
-}
-
-template <int NT, bool HAS_MASK, bool FAST>
+template <int NT, bool HAS_MASK>
 static void launch_sweep_wg(nnlm_handle *h, const SweepArgs &a, int nb)
 {
-    if (FAST) {
-        const int lds = sweep_wgf_lds_bytes(NT);
-        static int tail_env = getenv("NNLM_SWEEP_TAIL") ? atoi(getenv("NNLM_SWEEP_TAIL")) : 1;
-        if (NT >= 2 && tail_env && sweep_tail_coord(a.k) >= 0) { // k = 16 (NT - 1) + 1 or + 2: update waves with NT - 1 tiles
-            hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK, (NT >= 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            sweep_scd_wgf_kernel<NT, HAS_MASK, (NT >= 2)><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
-        } else {
-            hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, HAS_MASK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            sweep_scd_wgf_kernel<NT, HAS_MASK, false><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
-        }
-    } else {
-        const int lds = sweep_wg_lds_bytes(NT);
-        hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        sweep_scd_wg_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
-    }
+    const int lds = sweep_wg_lds_bytes(NT);
+    hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    sweep_scd_wg_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
 }
 
 // rank > 64: one wavefront per column, coordinates in LDS (k_generic.h); g_stride != 0: per-column Grams (missing values)
@@ -1065,17 +1049,19 @@ static int launch_sweep_generic(nnlm_handle *h, int method, const SweepArgs &a, 
 static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
     if (generic_rank(h)) return launch_sweep_generic(h, method, a, 0);
-    if (method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts) {
+    if (method == 1 && sweep_fast(h)) {
+        launch_sweep_q(h, a);
+        return NNLM_OK;
+    }
+    if (method == 1) {
         const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
-        const bool hm = a.mask != nullptr, fast = sweep_fast(h);
-        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts, fast ? 1 : 0);
+        if (nb <= 0) return NNLM_OK;
+        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
         h->consts_ready = false;
 #define NNLM_WG_SWEEP(NT_)                                                                                              \
     {                                                                                                                   \
-        if (hm && fast) launch_sweep_wg<NT_, true, true>(h, a, nb);                                                     \
-        else if (hm) launch_sweep_wg<NT_, true, false>(h, a, nb);                                                       \
-        else if (fast) launch_sweep_wg<NT_, false, true>(h, a, nb);                                                     \
-        else launch_sweep_wg<NT_, false, false>(h, a, nb);                                                              \
+        if (a.mask) launch_sweep_wg<NT_, true>(h, a, nb);                                                               \
+        else launch_sweep_wg<NT_, false>(h, a, nb);                                                                     \
     }
         switch (h->NKQ) {
         case 1: NNLM_WG_SWEEP(1) break;
@@ -1086,21 +1072,7 @@ static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 #undef NNLM_WG_SWEEP
         return NNLM_OK;
     }
-    if (method == 1 && use_mfma_sweep()) {
-        const int nb = (a.ncols + 63) / 64;
-        const bool hm = a.mask != nullptr;
-#define NNLM_MFMA_SWEEP(NT_)                                                               \
-    if (hm) sweep_scd_mfma_kernel<NT_, true><<<nb, 256, 0, h->stream>>>(a);                \
-    else sweep_scd_mfma_kernel<NT_, false><<<nb, 256, 0, h->stream>>>(a);
-        switch (h->NKQ) {
-        case 1: NNLM_MFMA_SWEEP(1) break;
-        case 2: NNLM_MFMA_SWEEP(2) break;
-        case 3: NNLM_MFMA_SWEEP(3) break;
-        default: NNLM_MFMA_SWEEP(4) break;
-        }
-#undef NNLM_MFMA_SWEEP
-        return NNLM_OK;
-    }
+    // Lee's multiplicative updates: sweep_ls_kernel, L lanes per column
     const int L = sweep_lanes_per_column(a.ncols);
     const int rneed = (h->k + L - 1) / L;
     if (L == 4) launch_sweep_l<2, 4>((rneed + 1) / 2, method, a, h->stream);      // R = 2..16, k <= 64
@@ -1640,25 +1612,23 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             h->Cx_elems = need;
         }
     }
-    // Dense SCD half-step of the split-fp16 mode on ONE stream (NNLM_ONE_STREAM=0: the two-stream flow below).  The small
-    // kernels between a sweep and the next cross product cost as much as they overlap (kernel timeline: 47 us from sweep end
-    // to cross product start, 24 us from its end to the next sweep, a third of it cross-stream event latency), so they are
-    // fused instead: gram_partial also yields max|factor| (no absmax pass, no memset), gram_reduce also writes the chain-wave
-    // constants of the sweep (no sweep_consts launch), and nothing waits on another stream.
-    static int one_stream_env = getenv("NNLM_ONE_STREAM") ? atoi(getenv("NNLM_ONE_STREAM")) : 1;
+    // Dense SCD half-step of the split-fp16 mode on ONE stream.  The small kernels between a sweep and the next cross product
+    // cost as much as they overlap (kernel timeline: 47 us from sweep end to cross product start, 24 us from its end to the
+    // next sweep, a third of it cross-stream event latency), so they are fused instead: gram_partial also yields max|factor|
+    // (no absmax pass, no memset), gram_reduce also writes the chain-wave constants of the strict sweep, and nothing waits on
+    // another stream.
     h->consts_ready = false;
-    if (one_stream_env && h->x16 && !h->sharded && !h->any_missing && method == 1 && use_mfma_sweep() && use_wg_sweep() && h->sweep_consts &&
-        !generic_rank(h)) {
-        // The fast sweep kernel (k_sweep_wgf.h) leaves max|x| and the Gram partial sums of the factor it solved -- the fixed
-        // factor of the NEXT half-step -- behind, computed from its LDS image (+1 us per sweep): the three kernels in front of
-        // the cross product are then factor16 (5 us), gram_fold (sum of the workgroups' slabs) and sweep_consts, none of
+    h->pack_ready = false;
+    if (h->x16 && !h->sharded && !h->any_missing && method == 1 && !generic_rank(h)) {
+        // The one-wavefront sweep kernel (k_sweep_q.h) leaves max|x| and the Gram partial sums of the factor it solved -- the fixed
+        // factor of the NEXT half-step -- behind, computed from its LDS image (+1 us per sweep): the kernels in front of the cross
+        // product are then factor16_fold (split copy + sum of the workgroups' slabs) and the sweep's operand image, neither of
         // which needs a fence -- gram_partial (12 us) and the "last block" step of gram_reduce_consts (most of its 15 us:
-        // __threadfence() is a cross-XCD cache write-back here) are gone.  NNLM_SWEEP_GRAM=0: the Gram kernels read the factor back.
-        static int sweep_gram_env = getenv("NNLM_SWEEP_GRAM") ? atoi(getenv("NNLM_SWEEP_GRAM")) : 1;
-        const bool fastsw = sweep_fast(h) && sweep_gram_env;
+        // __threadfence() is a cross-XCD cache write-back here) are gone.
+        const bool fastsw = sweep_fast(h);
         if (fastsw && !h->sg_slabs) {
             const int big = h->n > h->m ? h->n : h->m;
-            const int nwg = (big + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+            const int nwg = (big + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
             HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)nwg * h->KP * h->KP * 8));
         }
         unsigned *smax_w = fastsw ? h->maxbits + 4 + (h->sg_par ^ 1) : nullptr; // this half-step's sweep writes its max here
@@ -1676,8 +1646,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
                     factor16_fold_kernel<<<(unsigned)(h->KP * h->KP / 64 + (cnt + 1023) / 1024), 1024, 0, h->stream>>>(
                         Ym, ldm, lim, h->k, h->KP, ldm, h->maxbits + 4 + h->sg_par, h->scal_exp + 1, h->Y16, smax_w, h->sg_slabs, h->sg_nslabs, h->Graw);
                 }
-                sweep_consts_kernel<<<1, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], h->sweep_consts, 1);
-                h->consts_ready = true;
+                sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], (h->k + 3) / 4, h->sweepq_img);
+                h->pack_ready = true;
             }
             {
                 ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
@@ -1702,8 +1672,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             }
             prepare_factor16(h, which, mb, smax_w);
             gram_reduce_consts_kernel<<<h->KP * h->KP / 64, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw, h->k, reg[0], reg[1], h->sweep_consts,
-                                                                             h->maxbits + 3, mb_next, sweep_fast(h) ? 1 : 0);
-            h->consts_ready = true;
+                                                                             h->maxbits + 3, mb_next);
+            h->consts_ready = true; // (the strict kernel's constants; the one-wavefront kernel packs its operand image at launch)
         }
         {
             ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
@@ -1836,7 +1806,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         a.sweeps = h->sweeps + (speculative ? (h->sw_active ^ 1) : h->sw_active);
         a.col0 = 0;
         a.ocol0 = 0;
-        const bool sg = h->sg_request; // (only on the dense one-GPU split-fp16 path, where k_sweep_wgf.h runs)
+        const bool sg = h->sg_request; // (only on the dense one-GPU split-fp16 path, where k_sweep_q.h runs)
         h->sg_request = false;
         if (sg) {
             a.maxbits = h->maxbits + 4 + (h->sg_par ^ 1);
@@ -1899,7 +1869,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             int rcs = launch_sweep(h, method, a);
             if (rcs != NNLM_OK) return rcs;
             if (sg) { // the next half-step finds max and Gram partial sums of this factor
-                h->sg_nslabs = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
+                h->sg_nslabs = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
                 h->sg_par ^= 1;
                 h->sg_which = which;
                 h->sg_other = h->sg_prev; // the word this sweep did not touch

@@ -20,7 +20,7 @@ __global__ void k_layout(int *dl)
 // mode 0: 13 independent MFMAs per iteration; 1: one dependent MFMA chain; 2: 13 MFMAs + 1 VALU op on accumulator 0 (dependent);
 // 3: 16 independent v_mov_b32_dpp; 4: 8 dependent (v_max_f64 -> dpp mov pair -> v_fma_f64) rounds; 5: 16 independent fp64 FMAs;
 // 6: 13 MFMAs + 20 independent VALU FMAs interleaved by the compiler; 7: 13 MFMAs then 20 VALU
-__global__ void k_time(double *out, long long *cyc, int n, int mode)
+__global__ __launch_bounds__(256, 2) void k_time(double *out, long long *cyc, int n, int mode)
 {
     const int lane = threadIdx.x & 63;
     double acc[13], a = out[lane] + 1.0, b = 1e-9;
@@ -103,6 +103,40 @@ __global__ void k_time(double *out, long long *cyc, int n, int mode)
 #pragma unroll
         for (int i = 0; i < 4; i++) a += t[i][0] + t[i][3];
     }
+    else if (mode == 9) { // 13 independent MFMAs, 13 distinct A operands, one B
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[i], b, acc[i], 0, 0, 0);
+        }
+    } else if (mode == 10) { // distinct A and B
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[i], v[19 - (i % 7)], acc[i], 0, 0, 0);
+        }
+    } else if (mode == 11) { // out of place: D != C
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[i], b, acc[(i + 1) % 13], 0, 0, 0);
+        }
+    } else if (mode == 12) { // the step: 4 x (v_max, MFMA, dependent MFMA, MFMA, MFMA)
+        double x = out[lane] + 0.25, m = a;
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                double c;
+                asm volatile("v_max_f64 %0, -%1, -%2" : "=v"(c) : "v"(x), "v"(m));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3 * s] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[3 * s], b, acc[3 * s], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                m = __builtin_amdgcn_mfma_f64_4x4x4f64(v[12], c, acc[12], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3 * s + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[3 * s + 1], b, acc[3 * s + 1], 0, 0, 0);
+                acc[3 * s + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[3 * s + 2], b, acc[3 * s + 2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        a = m;
+    }
     long long s1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     double s = a;
 #pragma unroll
@@ -149,10 +183,10 @@ int main()
     hipMemset(d, 0, 4096 * 64 * 8);
     hipMalloc(&c, 16);
     const char *names[] = {"13 indep MFMA 4x4x4", "13 dependent MFMA 4x4x4", "13 MFMA + dependent v_max", "16 indep dpp mov", "8 x (max->2 dpp->fma) dependent",
-                           "16 indep fp64 FMA", "13 MFMA + 20 FMA (free order)", "13 MFMA then 20 FMA", "4 indep MFMA 16x16x4"};
-    const int per[] = {13, 13, 14, 16, 8, 16, 33, 33, 4};
+                           "16 indep fp64 FMA", "13 MFMA + 20 FMA (free order)", "13 MFMA then 20 FMA", "4 indep MFMA 16x16x4", "13 indep MFMA, distinct A", "13 indep MFMA, distinct A and B", "13 MFMA out of place", "step: 4 x (max, L, chain, L, L)"};
+    const int per[] = {13, 13, 14, 16, 8, 16, 33, 33, 4, 13, 13, 13, 20};
     for (int wpb : {1, 2}) // waves per SIMD on the measured CU: blocks of 256 x wpb threads
-        for (int mode = 0; mode < 9; mode++) {
+        for (int mode = 0; mode < 13; mode++) {
             const int n = 20000;
             for (int rep = 0; rep < 2; rep++) {
                 k_time<<<1, 64 * (wpb == 1 ? 1 : 5)>>>(d, c, n, mode); // 5 waves: wave 0 and wave 4 share SIMD 0
@@ -160,6 +194,19 @@ int main()
             }
             printf("[%s] %-34s: %.1f ticks/iter, %.2f ticks/op  (%.1f ns/iter)\n", wpb == 1 ? "lone wave " : "5 waves/CU", names[mode], (double)h[0] / n,
                    (double)h[0] / n / per[mode], 10.0 * h[1] / n);
+        }
+    // chip-wide: the step pattern (mode 12) and plain MFMAs (mode 0) on every SIMD, 1 / 2 / 3 wavefronts per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode : {0, 12, 9})
+        for (int grid : {1, 64, 256, 512, 768}) {
+            const int n = 20000; float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                hipEventRecord(e0);
+                k_time<<<grid, 256>>>(d, c, n, mode);
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            }
+            hipMemcpy(h, c, 16, hipMemcpyDeviceToHost);
+            printf("[grid %3d x 256] %-34s: kernel %.3f ms = %.1f ns/iter; block 0 wave 0: %.1f ticks/iter\n", grid, names[mode], ms, 1e6 * ms / n, (double)h[0] / n);
         }
     return 0;
 }

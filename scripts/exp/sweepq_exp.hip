@@ -1,0 +1,152 @@
+// Standalone check + timing of sweep_scd_q_kernel (k_sweep_q.h) against a CPU restatement of the SCD recurrence and
+// against sweep_scd_wgf_kernel (not part of the product).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o sweepq_exp sweepq_exp.hip ; ./sweepq_exp [ncols] [k] [max_iter]
+// #define SWEEPQ_DEBUG 1  (debug dumps: DUMP=col)
+#include "../../nnlm_amd/csrc/k_sweep_wgf.h"
+#include "../../nnlm_amd/csrc/k_sweep_q.h"
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include <random>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int NT, int NB> static int run(int ncols, int k, int max_iter)
+{
+    const int KP = 16 * NT;
+    const int ld = (ncols + 255) / 256 * 256;
+    const double r0 = 0.02, r1 = 0.01, r2 = 0.03;
+    const double tol = getenv("REL_TOL") ? atof(getenv("REL_TOL")) : 1e-9;
+    const bool masked = getenv("MASK") != nullptr;
+    std::mt19937_64 rng(1);
+    std::uniform_real_distribution<double> U(0, 1);
+    std::vector<double> G(KP * KP, 0.0), X((size_t)KP * ld, 0.0), C((size_t)KP * ld, 0.0), W((size_t)k * 500);
+    std::vector<unsigned long long> M(ld, 0ull);
+    for (auto &w : W) w = U(rng);
+    for (int q = 0; q < k; q++) for (int r = 0; r < k; r++) { double s = 0; for (int i = 0; i < 500; i++) s += W[q * 500 + i] * W[r * 500 + i]; G[q * KP + r] = s; }
+    for (int q = 0; q < k; q++) for (int c = 0; c < ncols; c++) { X[(size_t)q * ld + c] = U(rng); C[(size_t)q * ld + c] = 125 * U(rng); }
+    if (masked)
+        for (int c = 0; c < ncols; c++) {
+            for (int q = 0; q < k; q++) if (U(rng) < 0.15) M[c] |= 1ull << q;
+            if (c % 97 == 5) M[c] = ~0ull;
+        }
+    double *dG, *dX, *dC, *dO1, *dO2, *dK, *dI; unsigned long long *dS, *dM;
+    CK(hipMalloc(&dG, G.size() * 8)); CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dC, C.size() * 8)); CK(hipMalloc(&dS, 16)); CK(hipMalloc(&dM, M.size() * 8));
+    CK(hipMalloc(&dO1, X.size() * 8)); CK(hipMalloc(&dO2, X.size() * 8)); CK(hipMalloc(&dK, 16 * SWEEP_WG_CONSTS * 8)); CK(hipMalloc(&dI, sweepq_img_doubles(NB) * 8));
+    CK(hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dC, C.data(), C.size() * 8, hipMemcpyHostToDevice)); CK(hipMemset(dS, 0, 16)); CK(hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dO1, 0, X.size() * 8)); CK(hipMemset(dO2, 0, X.size() * 8));
+    SweepArgs a{};
+    a.X = dX; a.ldx = ld; a.ldo = ld; a.ocol0 = 0; a.col0 = 0; a.Graw = dG; a.KPg = KP; a.Cx = dC; a.slab_stride = (size_t)KP * ld; a.nslabs = 1; a.ldc = ld;
+    a.ncols = ncols; a.k = k; a.r0 = r0; a.r1 = r1; a.r2 = r2; a.mask = masked ? dM : nullptr; a.max_iter = max_iter; a.rel_tol = tol; a.op = nullptr; a.op_mode = 0; a.sweeps = dS;
+    if (getenv("GRAM")) {
+        const int nwg = (ncols + 47) / 48;
+        CK(hipMalloc(&a.gram_slabs, (size_t)nwg * KP * KP * 8));
+        CK(hipMalloc(&a.maxbits, 4)); CK(hipMemset(a.maxbits, 0, 4));
+    }
+    const int lds = sweep_wgf_lds_bytes(NT);
+    constexpr bool TAIL = (NB % 4 == 1) && NT >= 2; // k = 16 j + 1 .. 16 j + 4 -> tail form only for + 1, + 2; close enough for timing
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms1 = 0, ms2 = 0, msp = 0;
+    const bool run_old = !masked && k > 8 && sweep_tail_coord(k) == (TAIL ? (k / 16) * 16 : -1);
+    if (run_old) CK(hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, false, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int rep = 0; rep < 3; rep++) {
+        if (run_old) {
+            a.Xout = dO1;
+            sweep_consts_kernel<<<1, 256>>>(dG, KP, k, a.r0, a.r1, dK, 1);
+            hipEventRecord(e0);
+            sweep_scd_wgf_kernel<NT, false, TAIL><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
+            hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms1, e0, e1);
+        }
+        a.Xout = dO2;
+        CK(hipMemset(dS, 0, 16));
+        hipEventRecord(e0);
+        sweepq_pack_kernel<<<8, 256>>>(dG, KP, k, a.r0, a.r1, NB, dI);
+        hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&msp, e0, e1);
+        hipEventRecord(e0);
+        if (masked) sweep_scd_q_kernel<NT, NB, true><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
+        else sweep_scd_q_kernel<NT, NB, false><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
+        hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms2, e0, e1);
+    }
+    CK(hipGetLastError());
+    std::vector<double> O1(X.size()), O2(X.size());
+    unsigned long long S[2];
+    CK(hipMemcpy(O1.data(), dO1, X.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(O2.data(), dO2, X.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(S, dS, 16, hipMemcpyDeviceToHost));
+    // CPU restatement (reference arithmetic, src/base_algorithms.cpp:3-37) on a sample of the columns
+    auto edited = [&](int c, int kc) { double g = G[c * KP + kc]; if (c == kc && r0 != r1) g += r0 - r1; if (r1 != 0) g += r1; if (c == kc) g += 1e-16; return g; };
+    std::vector<double> Ge(k * k);
+    for (int q = 0; q < k; q++) for (int r = 0; r < k; r++) Ge[q * k + r] = edited(q, r);
+    double worst = 0, worst_old = 0, xm = 0; int wq = -1, wc = -1; long long sweeps_ref = 0; int nchk = 0;
+    const int stride = ncols > 4000 ? 37 : 1;
+    std::vector<char> checked(ncols, 0);
+    for (int c = 0; c < ncols; c += stride) {
+        std::vector<double> x(k), mu(k);
+        for (int q = 0; q < k; q++) x[q] = X[(size_t)q * ld + c];
+        for (int q = 0; q < k; q++) { double s = r2 - C[(size_t)q * ld + c]; for (int r = 0; r < k; r++) s += Ge[q * k + r] * x[r]; mu[q] = s; }
+        const unsigned long long mw = masked ? M[c] : 0ull, km = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+        int t = 0; double rel = 1 + tol;
+        if (!(masked && (mw & km) == km))
+            for (; t < max_iter && rel > tol; t++) {
+                rel = 0;
+                for (int q = 0; q < k; q++) {
+                    if ((mw >> q) & 1) continue;
+                    double tmp = x[q] - mu[q] / Ge[q * k + q]; if (tmp < 0) tmp = 0;
+                    if (tmp != x[q]) { const double d = tmp - x[q]; for (int r = 0; r < k; r++) mu[r] += d * Ge[r * k + q]; } else continue;
+                    const double e = 2 * fabs(x[q] - tmp) / (tmp + x[q] + 1e-16); if (e > rel) rel = e;
+                    x[q] = tmp;
+                }
+            }
+        sweeps_ref += t; nchk++; checked[c] = 1;
+        for (int q = 0; q < k; q++) {
+            const double d = fabs(O2[(size_t)q * ld + c] - x[q]);
+            if (d > worst) { worst = d; wq = q; wc = c; }
+            if (run_old) worst_old = fmax(worst_old, fabs(O1[(size_t)q * ld + c] - x[q]));
+            xm = fmax(xm, fabs(x[q]));
+        }
+    }
+    printf("NT=%d NB=%d ncols=%d k=%d max_iter=%d tol=%g mask=%d: wgf %.4f ms, q %.4f ms (pack %.4f ms); max|x| %.3g; q vs CPU max |diff| %.3e at (q=%d, col=%d); wgf vs CPU %.3e\n",
+           NT, NB, ncols, k, max_iter, tol, (int)masked, ms1, ms2, msp, xm, worst, wq, wc, worst_old);
+    if (getenv("DUMP")) {
+        const int c = atoi(getenv("DUMP"));
+        std::vector<double> x(k), mu(k);
+        for (int q = 0; q < k; q++) x[q] = X[(size_t)q * ld + c];
+        for (int q = 0; q < k; q++) { double s = r2 - C[(size_t)q * ld + c]; for (int r = 0; r < k; r++) s += Ge[q * k + r] * x[r]; mu[q] = s; }
+        for (int t = 0; t < max_iter; t++)
+            for (int q = 0; q < k; q++) { double tmp = x[q] - mu[q] / Ge[q * k + q]; if (tmp < 0) tmp = 0; const double d = tmp - x[q]; for (int r = 0; r < k; r++) mu[r] += d * Ge[r * k + q]; x[q] = tmp; }
+#ifdef SWEEPQ_DEBUG
+        {
+            double *dD; std::vector<double> D(64 * 16 + 16 * 6 * 64);
+            CK(hipMalloc(&dD, D.size() * 8)); CK(hipMemset(dD, 0, D.size() * 8));
+            SweepArgs b2 = a; b2.op = dD; b2.op_mode = 99; b2.Xout = dO2; b2.mask = nullptr;
+            sweep_scd_q_kernel<NT, NB, false><<<1, SWEEPQ_THREADS>>>(b2, dI);
+            CK(hipMemcpy(D.data(), dD, D.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> x0(k);
+            for (int q = 0; q < k; q++) x0[q] = X[(size_t)q * ld + c];
+            printf("  initial nu of column %d (q: cpu gpu):\n", c);
+            for (int q = 0; q < k; q++) { double s = r2 - C[(size_t)q * ld + c]; for (int r = 0; r < k; r++) s += Ge[q * k + r] * x0[r]; printf("   %2d: %.6f %.6f\n", q, s / Ge[q * k + q], D[q * 16 + c]); }
+            for (int B = 0; B < 2; B++) {
+                printf("  step %d, column %d, rows 0..3: (xb m0 m3 d xnew d_pend)\n", B, c);
+                for (int i = 0; i < 4; i++) { printf("   "); for (int v = 0; v < 6; v++) printf(" %.6f", D[1024 + B * 384 + v * 64 + 16 * i + c]); printf("\n"); }
+            }
+        }
+#endif
+        printf("  column %d after %d sweeps (q: cpu gpu x0):\n", c, max_iter);
+        for (int q = 0; q < k; q++) printf("   %2d: %.6f %.6f  (x0 %.6f)\n", q, x[q], O2[(size_t)q * ld + c], X[(size_t)q * ld + c]);
+    }
+    if (stride == 1) printf("  sweeps: GPU %llu, CPU %lld %s\n", S[0], sweeps_ref, (long long)S[0] == sweeps_ref ? "(equal)" : "(DIFFERENT)");
+    return 0;
+}
+int main(int argc, char **argv)
+{
+    const int ncols = argc > 1 ? atoi(argv[1]) : 10000, k = argc > 2 ? atoi(argv[2]) : 50, it = argc > 3 ? atoi(argv[3]) : 50;
+    const int NB = (k + 3) / 4;
+    switch (NB) {
+    case 3: return run<1, 3>(ncols, k, it);
+    case 5: return run<2, 5>(ncols, k, it);
+    case 8: return run<2, 8>(ncols, k, it);
+    case 12: return run<3, 12>(ncols, k, it);
+    case 13: return run<4, 13>(ncols, k, it);
+    case 16: return run<4, 16>(ncols, k, it);
+    default: printf("k not instantiated in the harness\n"); return 1;
+    }
+}
