@@ -144,17 +144,26 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
     bool act = in_range && !(HAS_MASK && ((mword & kmask) == kmask)); // arma::all(mask.col(j)) -> column skipped
     double acc[NB], x[NB];
-    // nu = ((L1 - c) + G x) / diag   (src/update_with_missing.cpp:39-41)
+    // nu = ((L1 - c) + G x) / diag   (src/update_with_missing.cpp:39-41).  All NB loads of a slab are issued together (a loop over the
+    // slabs INSIDE the loop over the blocks would be NB x nslabs dependent round trips to L2: 20 us of a 130 us kernel)
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int q = 4 * b + ri;
-        double cv = 0.0, xv = 0.0;
-        if (q < k) {
-            for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)q * a.ldc + cc];
-            xv = in_range ? a.X[(size_t)q * a.ldx + col] : 0.0;
+        acc[b] = 0.0;
+        x[b] = (q < k && in_range) ? a.X[(size_t)q * a.ldx + col] : 0.0;
+    }
+    for (int s = 0; s < a.nslabs; s++) {
+        const double *cs = a.Cx + (size_t)s * a.slab_stride + cc;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int q = 4 * b + ri;
+            acc[b] += (q < k) ? cs[(size_t)q * a.ldc] : 0.0;
         }
-        acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - cv : -cv) * rinv[q] : 0.0;
-        x[b] = xv;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int q = 4 * b + ri;
+        acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - acc[b] : -acc[b]) * rinv[q] : 0.0;
     }
     __syncthreads(); // operand image complete
     // this lane's operand values: lane (kA, blk, iA) reads entry li = 4 kA + iA of every operand (all four blk groups the same)

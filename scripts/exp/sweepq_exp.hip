@@ -1,8 +1,8 @@
-// Standalone check + timing of sweep_scd_q_kernel (k_sweep_q.h) against a CPU restatement of the SCD recurrence and
-// against sweep_scd_wgf_kernel (not part of the product).
+// Standalone check + timing of sweep_scd_q_kernel (k_sweep_q.h) against a CPU restatement of the SCD recurrence (not part of the product).
+// SLABS=3: the cross product arrives as three split-K slabs, as in the iteration loop; GRAM=1: the epilogue leaves max|x| and Gram slabs; OP=1: fp32 operand copy
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o sweepq_exp sweepq_exp.hip ; ./sweepq_exp [ncols] [k] [max_iter]
 // #define SWEEPQ_DEBUG 1  (debug dumps: DUMP=col)
-#include "../../nnlm_amd/csrc/k_sweep_wgf.h"
+#include "../../nnlm_amd/csrc/k_sweep.h"
 #include "../../nnlm_amd/csrc/k_sweep_q.h"
 #include <cstdio>
 #include <cmath>
@@ -19,6 +19,7 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
     const bool masked = getenv("MASK") != nullptr;
     std::mt19937_64 rng(1);
     std::uniform_real_distribution<double> U(0, 1);
+    const int nsl = getenv("SLABS") ? atoi(getenv("SLABS")) : 1;
     std::vector<double> G(KP * KP, 0.0), X((size_t)KP * ld, 0.0), C((size_t)KP * ld, 0.0), W((size_t)k * 500);
     std::vector<unsigned long long> M(ld, 0ull);
     for (auto &w : W) w = U(rng);
@@ -29,34 +30,33 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
             for (int q = 0; q < k; q++) if (U(rng) < 0.15) M[c] |= 1ull << q;
             if (c % 97 == 5) M[c] = ~0ull;
         }
-    double *dG, *dX, *dC, *dO1, *dO2, *dK, *dI; unsigned long long *dS, *dM;
-    CK(hipMalloc(&dG, G.size() * 8)); CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dC, C.size() * 8)); CK(hipMalloc(&dS, 16)); CK(hipMalloc(&dM, M.size() * 8));
-    CK(hipMalloc(&dO1, X.size() * 8)); CK(hipMalloc(&dO2, X.size() * 8)); CK(hipMalloc(&dK, 16 * SWEEP_WG_CONSTS * 8)); CK(hipMalloc(&dI, sweepq_img_doubles(NB) * 8));
+    double *dG, *dX, *dC, *dO1, *dO2, *dI; unsigned long long *dS, *dM;
+    CK(hipMalloc(&dG, G.size() * 8)); CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dC, C.size() * 8 * nsl)); CK(hipMalloc(&dS, 16)); CK(hipMalloc(&dM, M.size() * 8));
+    CK(hipMalloc(&dO1, X.size() * 8)); CK(hipMalloc(&dO2, X.size() * 8)); CK(hipMalloc(&dI, sweepq_img_doubles(NB) * 8));
     CK(hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dC, C.data(), C.size() * 8, hipMemcpyHostToDevice)); CK(hipMemset(dS, 0, 16)); CK(hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice));
+    {
+        std::vector<double> Cs(C.size());
+        for (int sl = 0; sl < nsl; sl++) { // slab sl = C * w_sl with weights that sum to one (powers of two: exact)
+            const double w = (nsl == 1) ? 1.0 : (sl == 0 ? 0.5 : 0.5 / (nsl - 1));
+            for (size_t i = 0; i < C.size(); i++) Cs[i] = C[i] * w;
+            CK(hipMemcpy(dC + (size_t)sl * C.size(), Cs.data(), C.size() * 8, hipMemcpyHostToDevice));
+        }
+    } CK(hipMemset(dS, 0, 16)); CK(hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemset(dO1, 0, X.size() * 8)); CK(hipMemset(dO2, 0, X.size() * 8));
     SweepArgs a{};
-    a.X = dX; a.ldx = ld; a.ldo = ld; a.ocol0 = 0; a.col0 = 0; a.Graw = dG; a.KPg = KP; a.Cx = dC; a.slab_stride = (size_t)KP * ld; a.nslabs = 1; a.ldc = ld;
+    a.X = dX; a.ldx = ld; a.ldo = ld; a.ocol0 = 0; a.col0 = 0; a.Graw = dG; a.KPg = KP; a.Cx = dC; a.slab_stride = (size_t)KP * ld; a.nslabs = nsl; a.ldc = ld;
     a.ncols = ncols; a.k = k; a.r0 = r0; a.r1 = r1; a.r2 = r2; a.mask = masked ? dM : nullptr; a.max_iter = max_iter; a.rel_tol = tol; a.op = nullptr; a.op_mode = 0; a.sweeps = dS;
+    float *dOp = nullptr;
+    if (getenv("OP")) { CK(hipMalloc(&dOp, (size_t)ld * KP * 4)); a.op = dOp; a.op_mode = 2; a.op_ld = KP; a.op_f64 = 0; }
     if (getenv("GRAM")) {
-        const int nwg = (ncols + 47) / 48;
+        const int nwg = (ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
         CK(hipMalloc(&a.gram_slabs, (size_t)nwg * KP * KP * 8));
         CK(hipMalloc(&a.maxbits, 4)); CK(hipMemset(a.maxbits, 0, 4));
     }
-    const int lds = sweep_wgf_lds_bytes(NT);
-    constexpr bool TAIL = (NB % 4 == 1) && NT >= 2; // k = 16 j + 1 .. 16 j + 4 -> tail form only for + 1, + 2; close enough for timing
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms1 = 0, ms2 = 0, msp = 0;
-    const bool run_old = !masked && k > 8 && sweep_tail_coord(k) == (TAIL ? (k / 16) * 16 : -1);
-    if (run_old) CK(hipFuncSetAttribute((const void *)sweep_scd_wgf_kernel<NT, false, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const bool run_old = false;
     for (int rep = 0; rep < 3; rep++) {
-        if (run_old) {
-            a.Xout = dO1;
-            sweep_consts_kernel<<<1, 256>>>(dG, KP, k, a.r0, a.r1, dK, 1);
-            hipEventRecord(e0);
-            sweep_scd_wgf_kernel<NT, false, TAIL><<<(ncols + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS, SWEEP_WG_THREADS, lds>>>(a, dK);
-            hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms1, e0, e1);
-        }
         a.Xout = dO2;
         CK(hipMemset(dS, 0, 16));
         hipEventRecord(e0);
@@ -104,7 +104,7 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
             xm = fmax(xm, fabs(x[q]));
         }
     }
-    printf("NT=%d NB=%d ncols=%d k=%d max_iter=%d tol=%g mask=%d: wgf %.4f ms, q %.4f ms (pack %.4f ms); max|x| %.3g; q vs CPU max |diff| %.3e at (q=%d, col=%d); wgf vs CPU %.3e\n",
+    printf("NT=%d NB=%d ncols=%d k=%d max_iter=%d tol=%g mask=%d: (unused %.4f) q %.4f ms (pack %.4f ms); max|x| %.3g; q vs CPU max |diff| %.3e at (q=%d, col=%d); (unused %.3e)\n",
            NT, NB, ncols, k, max_iter, tol, (int)masked, ms1, ms2, msp, xm, worst, wq, wc, worst_old);
     if (getenv("DUMP")) {
         const int c = atoi(getenv("DUMP"));
