@@ -17,7 +17,10 @@ error block inside the timed iterations).
 
 Prints ONE JSON line on rank 0 (see the task contract) with
   roofline            the kernel class with the largest share of the step (HIP-event timed inside this process),
-  roofline_secondary  the A-streaming cross product (HBM bound) when it is not the dominant class,
+  roofline_secondary  the A-streaming cross product of the H half-step (HBM bound) when it is not the dominant class,
+  other_configs       (N = 1, default config only) a few iterations each of the same problem in the strict fp64 mode (the .Call
+                      boundary's default) and of BASELINE configs[2] (KL + Lee) and configs[4] (10 % NA + L1/L2) in the fp32-operand
+                      mode: ms per step, dominant kernel class and its roofline fraction -- no extra CPU samples,
   step                whole-step fractions: SURVEY section 8d's bytes per iteration / time against the HBM peak, it/s against
                       its ceiling,
   cpu_baseline        oracle/nnlm_ref.c (OpenMP) on this box's host cores over the SAME iteration window (it starts from the
@@ -41,6 +44,10 @@ FP16_MFMA_PEAK_TF = 2500.0 # v_mfma_f32_16x16x32_f16 / bf16, dense (MI355X_MICRO
 # KL solvers: 3 plain + 1 transcendental fp32 instruction per element and coordinate = 14.9 cycles per 64 elements per SIMD
 # measured in isolation (scripts/exp/valu_exp.hip, "KL body packed"): 1024 SIMDs x 64 / 14.9 x 2.4 GHz
 KL_PEAK_GELEM = 1024 * 64 / 14.9 * 2.4
+# strict fp64 KL: ~12 fp64 VALU instructions per element and coordinate (rcp + 2 Newton steps + residual correction, the sums, the
+# refresh) at the fp64 vector rate of 16 lanes per cycle per SIMD
+KL64_PEAK_GELEM = 1024 * 16 / 12.0 * 2.4
+DTYPE_NAMES = {"f32": "f32 (A fp32; cross-product operands 22-bit split-fp16 pairs; Gram / sweeps fp64)", "f64": "f64"}
 N_, M_, K_ = 20000, 10000, 50
 INNER_TOL = float(os.environ.get("NNLM_BENCH_INNER_TOL", "1e-9"))  # (env: experiments only)
 SEED = 20250928
@@ -129,6 +136,131 @@ def cpu_baseline(A, Ww, Hw, k, cfg, iters, trace):
     return out, r
 
 
+def analyse(cfg, config_id, kern, n, m, k, s, world):
+    """Roofline blocks from the HIP-event scopes of one profiled run: (dominant class, secondary = the H half-step's cross product
+    when it is not the dominant one, all classes, shares of kernel time).  s = bytes per stored element of A."""
+    inner, method = cfg["inner"], cfg["method"]
+    x16 = s == 4   # fp32-operand mode: split-fp16 cross products, one kernel for both half-steps
+    # ---- algorithmic work per launch of each kernel class (DESIGN.md section 4 / SURVEY section 8d) ---------------------
+    # cross products (HBM): A once, the fixed factor once, the fp64 cross product once; at N ranks each rank streams 1/N of A
+    bytes_h = (n * m * s + k * n * s) / world + k * m * 8
+    bytes_w = (n * m * s + k * m * s) / world + k * n * 8
+    classes = {}
+    if method < 3:
+        for nm, by in (("xprod_h", bytes_h), ("xprod_w", bytes_w), ("xprod_w_err", bytes_w)):
+            if kern[nm]["ms_per_launch"]:
+                kname = ("xprod16_err_kernel" if nm == "xprod_w_err" else "xprod16_tn_kernel") if x16 else "xprod_tn_kernel"
+                classes[nm] = dict(bound="hbm", kernel=f"{nm} ({kname})", work=by, peak=HBM_PEAK_GBS, unit="GB/s", scale=1e9, pmc=kname)
+                if nm == "xprod_w_err":
+                    classes[nm]["note"] = "W half-step cross product that also evaluates the error sums of the trace iteration (no separate pass over A); same algorithmic bytes"
+        for nm, cols in (("sweep_h", m), ("sweep_w", n)):
+            if kern[nm]["ms_per_launch"]:
+                # the sweeps are a loop-carried recurrence (SURVEY 8d grants them no HBM roofline): priced as achieved fp64 arithmetic of
+                # the recurrence, inner*cols*k*(2k+8) flops per launch, against the fp64 matrix peak -- the rank-4 gradient updates run on
+                # v_mfma_f64_4x4x4 (16 of them per block of 4 coordinates and 16 columns), and 4x4x4 DGEMM issue is what bounds the kernel
+                # (one wavefront per SIMD: dependent-issue latency of the chain; two: the matrix pipe, which a second wavefront cannot overlap)
+                fl = inner * (cols / world) * k * (2 * k + 8)
+                knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else \
+                      ("sweep_scd_q_kernel" if s == 4 else "sweep_scd_wg_kernel")
+                pk = FP64_PEAK_TF
+                note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
+                        "flops = inner*cols*k*(2k+8)")
+                if cfg["na"]:
+                    # + the per-column Grams over the complement rows, 2 k^2 flops per missing entry.  F32 mode: they run on the fp16 matrix
+                    # cores as three split-fp16 products (a third of the dense fp16 peak per algorithmic flop); strict mode: fp64 MFMA.
+                    # The scope holds both kernels, so the peak is the blend that gives frac = (t_gram_floor + t_solver_floor) / t_measured.
+                    gfl = 2.0 * k * k * (n * m // 10)
+                    gpk = FP16_MFMA_PEAK_TF / 3.0 if s == 4 else FP64_PEAK_TF
+                    floor_s = gfl / (gpk * 1e12) + fl / (FP64_PEAK_TF * 1e12)
+                    fl += gfl
+                    pk = fl / floor_s / 1e12
+                    note += (" (fp64 vector peak) + 2k^2 per missing entry for the per-column Grams ("
+                             + ("3 split-fp16 products per flop on v_mfma_f32_16x16x32_f16: a third of the 2.5 PF dense fp16 peak" if s == 4 else "fp64 MFMA peak")
+                             + "); peak = total flops / (sum of the two floors)")
+                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None, note=note)
+    else:
+        for nm in ("sweep_h", "sweep_w"):
+            if kern[nm]["ms_per_launch"]:
+                el = float(n) * m * k * inner  # element-steps: every entry of A meets every coordinate once per sweep
+                if s == 4:
+                    classes[nm] = dict(bound="valu", kernel=f"{nm} (kl_tile_kernel)", work=el, peak=KL_PEAK_GELEM, unit="Gelem/s", scale=1e9, pmc=None,
+                                       note="fp32 VALU: 3 plain + 1 v_rcp_f32 per element and coordinate; peak = 14.9 cycles per 64 elements per SIMD "
+                                            "(scripts/exp/valu_exp.hip)")
+                else:
+                    classes[nm] = dict(bound="valu", kernel=f"{nm} (kl_reg64_kernel)", work=el, peak=KL64_PEAK_GELEM, unit="Gelem/s", scale=1e9, pmc=None,
+                                       note="fp64 VALU: ~12 fp64 instructions (correctly rounded quotient) per element and coordinate at 16 lanes per cycle per SIMD")
+    if kern["errors"]["ms_per_launch"] and "errors" not in classes:
+        classes["errors"] = dict(bound="hbm", kernel="errors (errors_f32_kernel / errors_kernel<double> / reduction of the fused sums)", work=n * m * s / world,
+                                 peak=HBM_PEAK_GBS, unit="GB/s", scale=1e9, pmc=None)
+
+    def block(nm):
+        c = classes[nm]
+        ms_l = kern[nm]["ms_per_launch"]
+        ach = c["work"] / (ms_l * 1e-3) / c["scale"]
+        traffic, src = (pmc_traffic(c["pmc"], config_id) if (c["pmc"] and world == 1) else (None, None))
+        b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
+                 traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
+        if "note" in c:
+            b["note"] = c["note"]
+        return b
+
+    total_k = sum(v["total_ms"] for v in kern.values()) or 1.0
+    shares = {kname: round(v["total_ms"] / total_k, 4) for kname, v in kern.items()}
+    ranked = sorted((nm for nm in classes if nm != "errors"), key=lambda nm: -kern[nm]["total_ms"])
+    roofline = block(ranked[0]) if ranked else None
+    if roofline:
+        roofline["share_of_kernel_time"] = shares[ranked[0]]
+    secondary = None
+    if "xprod_h" in classes and ranked and ranked[0] != "xprod_h":  # the plain A-streaming cross product (no fused error block in its launches)
+        secondary = block("xprod_h")
+        secondary["share_of_kernel_time"] = shares["xprod_h"]
+    all_blocks = {nm: block(nm) for nm in classes}
+    return roofline, secondary, all_blocks, shares
+
+
+SCOPES = ("xprod_h", "xprod_w", "xprod_w_err", "gram", "sweep_h", "sweep_w", "errors")
+
+
+def profile_scopes(h):
+    kern = {}
+    for name in SCOPES:
+        ms, cnt = h.profile_get(name)
+        kern[name] = dict(ms_per_launch=(ms / cnt if cnt else None), launches=cnt, total_ms=ms)
+    return kern
+
+
+def other_config(config_id, precision, n, m, k, local_rank, steps, warmup):
+    """A short run of another configuration on the same device (N = 1): ms per step, dominant kernel class, its fraction."""
+    import nnlm_amd
+    from nnlm_amd import _lib
+    cfg = dict(CONFIGS[config_id])
+    A, W0, H0 = make_inputs(n, m, k, cfg["na"])
+    with nnlm_amd.Handle(local_rank, _lib.PREC_F64 if precision == "f64" else _lib.PREC_F32) as h:
+        h.set_matrix(A)
+        del A
+        h.set_factors(k, W0, H0)
+        trace = cfg["trace"]
+        run_steps(h, cfg, warmup, trace)
+        h.sync()
+        t0 = time.perf_counter()
+        r = run_steps(h, cfg, steps, trace)
+        h.sync()
+        dt = time.perf_counter() - t0
+        h.profile_reset()
+        h.profile_enable(True)
+        run_steps(h, cfg, steps, trace)
+        h.sync()
+        kern = profile_scopes(h)
+        h.profile_enable(False)
+    roof, _, blocks, shares = analyse(cfg, config_id, kern, n, m, k, 8 if precision == "f64" else 4, 1)
+    return dict(workload=cfg["name"].format(n=n, m=m, k=k), dtype=DTYPE_NAMES[precision], steps=steps, warmup=warmup, trace=trace,
+                ms_per_step=1e3 * dt / steps, iterations_per_s=steps / dt, final_mse=float(r["mse_error"][-1]),
+                dominant=dict(kernel=roof["kernel"], bound=roof["bound"], frac=roof["frac"], ms_per_launch=roof["ms_per_launch"],
+                              share_of_kernel_time=roof["share_of_kernel_time"]) if roof else None,
+                kernels_ms_per_launch={kk: v["ms_per_launch"] for kk, v in kern.items() if v["ms_per_launch"]},
+                roofline_frac={kk: round(v["frac"], 4) for kk, v in blocks.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +273,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2, help="outer iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions (the first one is `value`; all are listed)")
     ap.add_argument("--size", default=None, help="n,m,k override for quick experiments (reported in config)")
+    ap.add_argument("--others", type=int, default=1, help="1: after the headline (N = 1, default config) also time strict-fp64 config 2 and fp32 configs 3 and 5 "
+                                                          "for a few iterations each -> other_configs; 0: skip")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -216,10 +350,7 @@ def main():
     run_steps(h, cfg, args.steps, trace)
     barrier()
     prof_elapsed = time.perf_counter() - t0
-    kern = {}
-    for name in ("xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors"):
-        ms, cnt = h.profile_get(name)
-        kern[name] = dict(ms_per_launch=(ms / cnt if cnt else None), launches=cnt, total_ms=ms)
+    kern = profile_scopes(h)
     h.profile_enable(False)
 
     # GPU mse after `cpu_iters` iterations from the warmed state (what the CPU sample reproduces)
@@ -240,74 +371,8 @@ def main():
         return
 
     s = 8 if args.precision == "f64" else 4
-    x16 = s == 4 and os.environ.get("NNLM_XPROD", "") != "f32"   # split-fp16 cross products: one kernel for both half-steps
     inner, method = cfg["inner"], cfg["method"]
-    # ---- algorithmic work per launch of each kernel class (DESIGN.md section 4 / SURVEY section 8d) ---------------------
-    # cross products (HBM): A once, the fixed factor once, the fp64 cross product once; at N ranks each rank streams 1/N of A
-    bytes_h = (n * m * s + k * n * s) / world + k * m * 8
-    bytes_w = (n * m * s + k * m * s) / world + k * n * 8
-    classes = {}
-    if method < 3:
-        for nm, by in (("xprod_h", bytes_h), ("xprod_w", bytes_w)):
-            if kern[nm]["ms_per_launch"]:
-                # (trace iterations run the fused cross-product + error-block kernel in xprod_w: its launches are averaged in)
-                kname = "xprod16_tn_kernel" if x16 else ("xprod_nt_kernel" if nm == "xprod_w" else "xprod_tn_kernel")
-                classes[nm] = dict(bound="hbm", kernel=f"{nm} ({kname})", work=by, peak=HBM_PEAK_GBS, unit="GB/s", scale=1e9, pmc=kname)
-        for nm, cols in (("sweep_h", m), ("sweep_w", n)):
-            if kern[nm]["ms_per_launch"]:
-                # the sweeps are a loop-carried recurrence (SURVEY 8d grants them no HBM/MFMA roofline): priced as achieved fp64
-                # arithmetic of the recurrence, inner*cols*k*(2k+8) flops per launch, against the fp64 matrix/vector peak
-                fl = inner * (cols / world) * k * (2 * k + 8)
-                knm = "na_gram_f16_kernel + colsolve_fast_kernel" if cfg["na"] else "sweep_scd_wgf_kernel"
-                pk = FP64_PEAK_TF
-                note = "latency bound: inner*k dependent coordinate steps per column; flops = inner*cols*k*(2k+8)"
-                if cfg["na"]:
-                    # + the per-column Grams over the complement rows, 2 k^2 flops per missing entry.  F32 mode: they run on the fp16 matrix
-                    # cores as three split-fp16 products (a third of the dense fp16 peak per algorithmic flop); strict mode: fp64 MFMA.
-                    # The scope holds both kernels, so the peak is the blend that gives frac = (t_gram_floor + t_solver_floor) / t_measured.
-                    gfl = 2.0 * k * k * (n * m // 10)
-                    gpk = FP16_MFMA_PEAK_TF / 3.0 if s == 4 else FP64_PEAK_TF
-                    floor_s = gfl / (gpk * 1e12) + fl / (FP64_PEAK_TF * 1e12)
-                    fl += gfl
-                    pk = fl / floor_s / 1e12
-                    note += (" (fp64 vector peak) + 2k^2 per missing entry for the per-column Grams ("
-                             + ("3 split-fp16 products per flop on v_mfma_f32_16x16x32_f16: a third of the 2.5 PF dense fp16 peak" if s == 4 else "fp64 MFMA peak")
-                             + "); peak = total flops / (sum of the two floors)")
-                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None, note=note)
-    else:
-        for nm in ("sweep_h", "sweep_w"):
-            if kern[nm]["ms_per_launch"]:
-                el = float(n) * m * k * inner  # element-steps: every entry of A meets every coordinate once per sweep
-                classes[nm] = dict(bound="valu", kernel=f"{nm} (wh_store_kernel + kl_tile_kernel)", work=el, peak=KL_PEAK_GELEM, unit="Gelem/s", scale=1e9, pmc=None,
-                                   note="fp32 VALU: 3 plain + 1 v_rcp_f32 per element and coordinate; peak = 14.9 cycles per 64 elements per SIMD "
-                                        "(scripts/exp/valu_exp.hip)")
-    if kern["errors"]["ms_per_launch"] and "errors" not in classes:
-        classes["errors"] = dict(bound="hbm", kernel="errors (errors_f32_kernel / reduction of the fused sums)", work=n * m * s / world, peak=HBM_PEAK_GBS,
-                                 unit="GB/s", scale=1e9, pmc=None)
-
-    def block(nm):
-        c = classes[nm]
-        ms_l = kern[nm]["ms_per_launch"]
-        ach = c["work"] / (ms_l * 1e-3) / c["scale"]
-        traffic, src = (pmc_traffic(c["pmc"], args.config) if (c["pmc"] and world == 1) else (None, None))
-        b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
-                 traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
-        if "note" in c:
-            b["note"] = c["note"]
-        return b
-
-    total_k = sum(v["total_ms"] for v in kern.values()) or 1.0
-    shares = {kname: round(v["total_ms"] / total_k, 4) for kname, v in kern.items()}
-    ranked = sorted((nm for nm in classes if nm != "errors"), key=lambda nm: -kern[nm]["total_ms"])
-    roofline = block(ranked[0]) if ranked else None
-    if roofline:
-        roofline["share_of_kernel_time"] = shares[ranked[0]]
-    secondary = None
-    xp = [nm for nm in ranked if classes[nm]["bound"] == "hbm"]
-    if xp and xp[0] != ranked[0]:
-        secondary = block(xp[0])
-        secondary["share_of_kernel_time"] = shares[xp[0]]
-    all_blocks = {nm: block(nm) for nm in classes}
+    roofline, secondary, all_blocks, shares = analyse(cfg, args.config, kern, n, m, k, s, world)
 
     # whole step against SURVEY 8d's per-iteration figures (config 2): bytes A twice + factors, +A once on trace iterations
     ms_step = 1e3 * elapsed / args.steps
@@ -326,6 +391,16 @@ def main():
                          gpu_average_epoch=float(np.sum(gpu_check["average_epoch"]) / args.cpu_iters), cpu_average_epoch=cpu["average_epoch"])
 
     ms_all = [1e3 * t / args.steps for t in times]
+    # the rest of the picture in the same line (task 3): the .Call boundary's default mode and the other single-GPU configs
+    others = None
+    if args.others and world == 1 and not force_comm and args.config == 2 and args.precision == "f32" and args.protocol == "default":
+        h.close()
+        others = {}
+        for key, cid, pr, st, wu in (("config2_strict_f64", 2, "f64", 6, 2), ("config3_kl_lee_f32", 3, "f32", 4, 1), ("config5_na_reg_f32", 5, "f32", 6, 2)):
+            try:
+                others[key] = other_config(cid, pr, n, m, k, local_rank, st, wu)
+            except Exception as e:  # (never lose the headline over a secondary measurement)
+                others[key] = dict(error=f"{type(e).__name__}: {e}")
     out = {
         "metric": "nnmf iterations/sec + final MSE, dense A 20000x10000 k=50, 1/2/4/8 GPU",
         "value": args.steps / elapsed,
@@ -337,17 +412,15 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": args.precision,
+        "dtype": DTYPE_NAMES[args.precision],
         "data": "synthetic",
         "final_mse": final_mse,
         "config": {"workload": cfg["name"].format(n=n, m=m, k=k), "n": n, "m": m, "k": k, "method": method,
                    "inner_max_iter": inner, "inner_rel_tol": INNER_TOL, "trace": trace, "protocol": args.protocol, "rel_tol": -1,
                    "reg": cfg["reg"],
-                   "arith": (("A fp32 (4 B/element); cross products: operands as split fp16 pairs (hi + lo*2^-11, 22 bits) on "
-                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation folded into fp64 every 256 elements"
-                              if os.environ.get("NNLM_XPROD", "") != "f32" else
-                              "A + cross-product GEMMs fp32 MFMA (fp64 flush every 256)") + "; Gram/mu/sweeps fp64; KL solvers fp32 state" if s == 4
-                             else "all fp64 (v_mfma_f64_16x16x4_f64)"),
+                   "arith": ("A fp32 (4 B/element); cross products: operands as split fp16 pairs (hi + lo*2^-11, 22 bits) on "
+                             "v_mfma_f32_16x16x32_f16 with fp32 accumulation folded into fp64 every 256 elements; Gram/mu/sweeps fp64; "
+                             "KL solvers fp32 state" if s == 4 else "all fp64 (v_mfma_f64_16x16x4_f64, v_mfma_f64_4x4x4)"),
                    "parallelism": ((f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
                                     if os.environ.get("NNLM_SHARD_DENSE", "") == "reduce" and method < 3 and not cfg["na"] else
                                     f"columns sharded x{world} (cross product, Gram, sweep of a rank's columns) + 1 RCCL all-gather per half-step")
@@ -357,6 +430,7 @@ def main():
         "roofline": roofline,
         "roofline_secondary": secondary,
         "roofline_all": all_blocks,
+        "other_configs": others,
         "step": step,
         "cpu_baseline": cpu,
         "mse_check": mse_check,

@@ -40,8 +40,10 @@ extern "C" {
 
 /* arithmetic modes: what A is stored as in HBM and which MFMA the cross-products run on.
  * Gram matrices, mu = G*x - c, the coordinate sweeps and all reductions are fp64 in both modes. */
-#define NNLM_PREC_F32 0 /* A and GEMM operands fp32, v_mfma_f32_16x16x4_f32, fp32 partial sums flushed into fp64 */
-#define NNLM_PREC_F64 1 /* A and GEMM operands fp64, v_mfma_f64_16x16x4_f64 (strict-parity mode) */
+#define NNLM_PREC_F32 0 /* A fp32 in HBM (4 bytes per element); the A-streaming cross products take their operands as split-fp16 pairs
+                         * (hi + lo * 2^-11: 22 significant bits) on v_mfma_f32_16x16x32_f16, fp32 partial sums flushed into fp64
+                         * every 256 elements; KL solvers keep their state in fp32 */
+#define NNLM_PREC_F64 1 /* A and GEMM operands fp64, v_mfma_f64_16x16x4_f64 (strict-parity mode; the default of the one-shot entries) */
 
 /*
  * Host callbacks = the R API points the reference touches from its main thread.

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) acc[a][b] = M::mma(wa[a], hb[b], acc[a][b]);
+            for (int b = 0; b < 2; b++) acc[a][b] = M::mma(hb[b], wa[a], acc[a][b]); // M = column j, N = row i
     }
 
     double s2 = 0.0, skl = 0.0;
@@ -49,10 +49,13 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            const int j = jb + 16 * b + l15;
+            // accumulator layout: column index N = l15 <-> 16 CONSECUTIVE rows i of one column j of A per lane group: 128-byte
+            // (fp64) / 64-byte segments.  (Rounds 1-2 had the roles the other way round -- 16 lanes on 16 different columns, 32-byte
+            // pieces of 16 cache lines per load: 1.2 ms for the 1.6 GB of the strict mode's A.)
+            const int i = ib + 16 * a + l15;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = ib + 16 * a + M::row_of(lane, r);
+                const int j = jb + 16 * b + M::row_of(lane, r);
                 bool valid = (i < n) && (j < m);
                 if (miss && valid) valid = !((miss[(size_t)j * words + (i >> 5)] >> (i & 31)) & 1u);
                 const T av = A[(size_t)j * lda + i];

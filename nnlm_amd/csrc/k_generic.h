@@ -194,9 +194,6 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(const SweepArgs a, s
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
             else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
-            else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);

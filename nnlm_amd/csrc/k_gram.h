@@ -181,9 +181,6 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
     if (op_mode == 1) {
         if (op_f64) ((double *)op)[(size_t)q * op_ld + col] = v;
         else ((float *)op)[(size_t)q * op_ld + col] = (float)v;
-    } else if (op_mode == 2) {
-        if (op_f64) ((double *)op)[(size_t)col * op_ld + q] = v;
-        else ((float *)op)[(size_t)col * op_ld + q] = (float)v;
     }
 }
 

@@ -1,23 +1,22 @@
-// k_kl.h -- per-column solvers for the KL-divergence methods: kl_update_kernel (strict fp64, state in registers),
-// kl_tile_kernel (fp32-operand mode), kl_stream_kernel (no size limits).
+// k_kl.h -- per-column solvers for the KL-divergence methods: kl_reg64_kernel (strict fp64 mode), kl_tile_kernel (fp32-operand
+// mode), kl_stream_kernel (no size limits).
 //
 // Reference: scd_kl_update (src/base_algorithms.cpp:71-116) and lee_kl_update (src/base_algorithms.cpp:119-151) as
 // called from update() (src/update_with_missing.cpp:47-49) and, with the contraction restricted to the finite
 // entries of the column, from update_with_missing() (src/update_with_missing.cpp:118-133).
 //
-// One 512-thread block per column j of the factor being solved.  The length-p state vector of the column
-// (y = Yt^T x, "Ajt"/"wh" in the reference) and the data column b stay in registers, EPT elements per thread;
-// the k coordinates are visited sequentially (loop-carried, exactly as in the reference) and each visit is
-//   one coalesced read of row q of the fixed factor  ->  per-thread partial sums  ->  block reduction
-//   ->  the scalar update (computed redundantly by every thread)  ->  rank-1 refresh of y in registers.
+// A 512-thread block owns one or a few columns j of the factor being solved.  The length-p state vector of a column
+// (y = Yt^T x, "Ajt"/"wh" in the reference) and the data column b stay in registers; the k coordinates are visited
+// sequentially (loop-carried, exactly as in the reference) and each visit is
+//   one read of row q of the fixed factor  ->  per-thread partial sums  ->  block reduction
+//   ->  the scalar update  ->  rank-1 refresh of y in registers.
 // Missing entries (NA path) simply carry weight 0 (they are absent from Wt.cols(non_missing) in the
 // reference); sumW is summed over the same index set inside the same reduction (src/update_with_missing.cpp:122,130).
 // Arithmetic is n*m*k fp64 divides per sweep: VALU/transcendental bound, not HBM bound.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
-#define KL_THREADS 512
-#define KL_MAX_P (KL_THREADS * 64)
 
 struct KlArgs {
     const double *X; // [KP][ldx] master of the factor being solved, read
@@ -43,132 +42,450 @@ struct KlArgs {
     int col0 = 0, ldo = 0, ocol0 = 0;
 };
 
-// block-wide sum of NV values, identical result in every thread; `red` is [2][NV][8] doubles, `par` alternates 0/1
-template <int NV>
-__device__ static inline void kl_block_sum(double (&v)[NV], double *red, int par)
+// ==================================================================================================================
+// kl_reg64_kernel -- the KL solvers of the strict fp64 mode (replaces kl_update_kernel<double, EPT, METHOD>, which kept the row
+// of the fixed factor in registers between its two passes: 256 VGPRs + up to 1152 bytes of scratch per lane, 52 ms per half-step
+// at config 3).  Same iteration, the reference's arithmetic (fp64 state, correctly rounded quotients), organised like
+// kl_tile_kernel:
+//   * a 512-thread block owns C columns; the state vector y and the data column b of each column stay in registers as double2
+//     chunks (thread t owns chunks t, t + 512, ...: 16-byte loads from contraction-contiguous layouts -- A / What64 for the H
+//     half-step, the transposed copy AT / What64^T for the W half-step); C * EPT2 <= 20 chunks = 160 state registers;
+//   * the starting states y = Yt^T x of ALL columns come from one fp64 GEMM (wh_store64_kernel), not from k passes per column;
+//   * row q of the fixed factor is read ONCE per step from L2 (the master, fp64) in pass A, parked in LDS (16 bytes per slot,
+//     every thread reads back only its own slots: no barrier) and picked up again by pass B -- the row is 160 KB at p = 20000,
+//     the LDS holds the first ELDS chunks (144 KB), the last ones stay in registers;
+//   * b / (y + eps) = b r (1 + e + e^2 ...) from v_rcp_f64 + two Newton steps + one residual correction: the correctly rounded
+//     quotient for these operands (y + eps >= 1e-16, no scaling cases) in 8 instructions instead of the 14 of the IEEE sequence;
+//   * the row sums of the fixed factor come precomputed (kl_sumw_kernel / kl_sumw_cols_kernel), missing entries carry b = 0.
+// fp64 VALU bound: ~12 instructions per element and coordinate = 3.7 ms per half-step at config 3 at the full fp64 rate.
+struct Kl64Args {
+    const double *Adata; // column c at Adata + c * lda, contraction index contiguous
+    size_t lda;          // (even)
+    const double *Yinit; // same layout: starting state vectors (wh_store64_kernel)
+    const double *Y;     // [k][ldy] master of the fixed factor, contraction index contiguous
+    int ldy;
+    int p, ncols, k;
+    const double *X;
+    double *Xout;
+    int ldx;
+    int colbase, ldo, ocol0;
+    const double *sumw;      // [k]
+    const double *sumw_cols; // [ncols][ldsw] or NULL
+    int ldsw;
+    double r0, r1, r2;
+    const unsigned long long *mask; // [ncols] (rank <= 64) or NULL
+    unsigned max_iter;
+    double rel_tol;
+    void *op; // fp64 operand copy [KP][op_ld] (op_mode 1) or none
+    int op_mode, op_ld;
+    unsigned long long *sweeps;
+};
+#define KL64_THREADS 512
+#define KL64_ELDS_MAX 19 // chunks of a row the LDS holds (19 * 8 KB = 152 KB; the 20th stays in registers)
+__host__ __device__ static inline size_t kl64_lds_bytes(int EPT2, int C, int k)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NV; c++) {
-        v[c] = wave_sum(v[c]);
-        if (lane == 0) red[(par * NV + c) * 8 + wave] = v[c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NV; c++) {
-        const double *r = red + (par * NV + c) * 8;
-        v[c] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const int elds = EPT2 < KL64_ELDS_MAX ? EPT2 : KL64_ELDS_MAX;
+    return (size_t)elds * KL64_THREADS * 16 + (size_t)2 * C * k * 8 + (size_t)2 * 2 * C * 8 * 8;
+}
+// a block-uniform double as a scalar (SGPR pair): the per-column bookkeeping is identical in every lane, and 160 state registers
+// leave no room for per-lane copies of it
+__device__ static inline double kl64_uni(double v)
+{
+    int2 p = __builtin_bit_cast(int2, v);
+    p.x = __builtin_amdgcn_readfirstlane(p.x);
+    p.y = __builtin_amdgcn_readfirstlane(p.y);
+    return __builtin_bit_cast(double, p);
+}
+// correctly rounded a / d for d >= 1e-16 finite, |a| moderate: reciprocal, two Newton steps, one residual correction
+__device__ static inline double kl64_div(double a, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-d, q, a), r, q);
+}
+
+template <int I, int N, class F> __device__ __forceinline__ void klq_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        klq_for<I + 1, N>(f);
     }
 }
 
-template <typename T, int EPT, int METHOD>
-__global__ __launch_bounds__(KL_THREADS) void kl_update_kernel(const KlArgs a)
+template <int EPT2, int C, int METHOD>
+__global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a)
 {
-    __shared__ double xs[64];
-    __shared__ double red[2 * 3 * 8];
-    const int tid = threadIdx.x;
-    const int col = a.col0 + blockIdx.x;
-    const int k = a.k, p = a.p;
+    constexpr int NV = (METHOD == 4) ? 1 : 2;
+    constexpr int ELDS = EPT2 < KL64_ELDS_MAX ? EPT2 : KL64_ELDS_MAX, EREG = EPT2 - ELDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char kl64_smem[];
+    f64x2 *rowl = (f64x2 *)kl64_smem;                                  // [ELDS][512] this step's row, parked between the passes
+    double *xs = (double *)(kl64_smem + (size_t)ELDS * KL64_THREADS * 16); // [C][k]
+    double *sws = xs + C * a.k;                                        // [C][k]
+    double *red = sws + C * a.k;                                       // [2][NV * C][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: scalar address arithmetic)
+    const int k = a.k, p = a.p, P2 = (p + 1) / 2; // double2 chunks of a row that hold data
+    const int col0 = a.colbase + blockIdx.x * C;
 
-    unsigned long long mword = 0ull;
-    if (a.mask) mword = a.mask[col];
-    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-    const bool skipcol = a.mask && ((mword & kmask) == kmask); // all coordinates masked: 0 sweeps, values copied through
-
-    if (tid < 64) xs[tid] = (tid < k) ? a.X[(size_t)tid * a.ldx + col] : 0.0;
-    __syncthreads();
-
-    double y[EPT];
-    T b[EPT];
-    unsigned long long vbits = 0ull; // bit e: element e of this thread takes part
-    const T *Acol = (const T *)a.A + (size_t)col * a.a_col_stride;
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        const int i = e * KL_THREADS + tid;
-        bool valid = i < p;
-        if (valid && a.bits) valid = !((a.bits[(size_t)col * a.words + (i >> 5)] >> (i & 31)) & 1u);
-        b[e] = valid ? Acol[(size_t)i * a.a_i_stride] : (T)0;
-        if (valid) vbits |= (1ull << e);
-        y[e] = 0.0;
+    for (int e = tid; e < C * k; e += KL64_THREADS) {
+        const int c = e / k, q = e - c * k, col = col0 + c;
+        xs[e] = (col < a.ncols) ? a.X[(size_t)q * a.ldx + col] : 0.0;
+        sws[e] = (col < a.ncols) ? (a.sumw_cols ? a.sumw_cols[(size_t)col * a.ldsw + q] : a.sumw[q]) : 1.0;
     }
-    double S = 0.0;
-    for (int q = 0; q < k; q++) { // y = Yt^T x, S = sum(x)
-        const double xq = xs[q];
-        S += xq;
+    f64x2 y[C][EPT2], b[C][EPT2];
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int i = e * KL_THREADS + tid;
-            const double w = ((vbits >> e) & 1ull) ? a.Y[(size_t)q * a.ldy + i] : 0.0;
-            y[e] = __builtin_fma(w, xq, y[e]);
+    for (int c = 0; c < C; c++) {
+        const int col = (col0 + c < a.ncols) ? col0 + c : col0;
+        const f64x2 *Ac = (const f64x2 *)(a.Adata + (size_t)col * a.lda), *Yc = (const f64x2 *)(a.Yinit + (size_t)col * a.lda);
+#pragma unroll
+        for (int e = 0; e < EPT2; e++) {
+            const int i2 = e * KL64_THREADS + tid;
+            const bool valid = i2 < P2 && col0 + c < a.ncols;
+            b[c][e] = valid ? Ac[i2] : f64x2{0.0, 0.0};
+            y[c][e] = valid ? Yc[i2] : f64x2{1.0, 1.0};
+            if (valid && 2 * i2 + 1 >= p) b[c][e][1] = 0.0, y[c][e][1] = 1.0; // (odd contraction length: the pad element)
         }
     }
-
-    double rel = 1.0 + a.rel_tol;
-    unsigned t = 0;
+    // per-column bookkeeping, identical in every thread (block-uniform)
+    bool live[C];
+    unsigned long long mword[C];
+    double S[C];
+    unsigned tdone[C];
+    bool run[C], flag[C];
+    __syncthreads();
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        live[c] = col0 + c < a.ncols;
+        mword[c] = (a.mask && live[c]) ? a.mask[col0 + c] : 0ull;
+        const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+        if (a.mask && (mword[c] & kmask) == kmask) live[c] = false; // all coordinates masked: 0 sweeps (src/update_with_missing.cpp:33)
+        S[c] = 0.0;
+        for (int q = 0; q < k; q++) S[c] += xs[c * k + q];
+        S[c] = kl64_uni(S[c]);
+        tdone[c] = 0;
+        run[c] = live[c] && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol;
+        flag[c] = false;
+        any = any || run[c];
+    }
+    // The row of the fixed factor comes through LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so all ELDS chunks of
+    // the NEXT row are in flight while pass B and the reduction of this step run -- with register-destination loads two chunks
+    // ahead the kernel sat at 6.5 TB/s of L2 reads, latency x bytes in flight).  One row buffer: chunk e of the next row is requested
+    // into its slot right after pass B has read chunk e of this row back; every thread reads only slots its own wavefront loaded, so
+    // `s_waitcnt vmcnt(0)` in front of pass A is all the synchronisation the rows need.  The instruction is written out (scalar base,
+    // one per-lane offset register, LDS base in M0): the compiler's wait-count pass would otherwise put a vmcnt(0) in front of every
+    // LDS read that follows it.  Chunks beyond the LDS (EREG of them) are plain loads at the top of pass A, used at its end.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)kl64_smem + (unsigned)wave * 1024u;
+    const int voff = lane * 16, L2c = a.ldy / 2; // (chunks at or beyond L2c lie outside the row: never loaded, their slots stay zero)
+    for (int i = tid; i < ELDS * KL64_THREADS; i += KL64_THREADS)
+        if (i >= L2c) rowl[i] = f64x2{0.0, 0.0};
+    auto issue_chunk = [&](int qq, int e) {
+        const unsigned char *src = (const unsigned char *)(a.Y + (size_t)qq * a.ldy) + (size_t)e * (KL64_THREADS * 16) + (size_t)wave * 1024; // wave-uniform
+        const unsigned long long sp = (unsigned long long)src;
+        const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)sp);
+        const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)e * (KL64_THREADS * 16)));
+        if (e * KL64_THREADS + tid < L2c) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(su), "s"(du) : "memory");
+    };
+    auto issue_row = [&](int qq) {
+#pragma unroll
+        for (int e = 0; e < ELDS; e++) issue_chunk(qq, e);
+    };
+    __syncthreads(); // (the zeroed slots)
     int par = 0;
-    for (; !skipcol && t < a.max_iter && rel > a.rel_tol; t++) {
-        rel = 0.0;
+    if (any) issue_row(0);
+    while (any) {
+#pragma unroll
+        for (int c = 0; c < C; c++) flag[c] = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
-            if ((mword >> q) & 1ull) continue;
-            const double xq = xs[q]; // read BEFORE the reduction's barrier: thread 0 rewrites xs[q] after it
-            double w[EPT];
-            double v[3] = {0.0, 0.0, 0.0};
+            const int qn = (q + 1 < k) ? q + 1 : 0; // next row (row 0 again for a sweep that may follow)
+            bool doq[C], anyq = false;
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = e * KL_THREADS + tid;
-                w[e] = ((vbits >> e) & 1ull) ? a.Y[(size_t)q * a.ldy + i] : 0.0;
-                if (METHOD == 4) {
-                    v[0] += w[e] * ((double)b[e] / (y[e] + NNLM_TINY)); // Wt.row(k) * (Aj / (wh + eps)), :141
-                } else {
-                    const double u = w[e] / (y[e] + NNLM_TINY);          // mu, :97
-                    v[0] += (double)b[e] * (u * u);                      // a, :98
-                    v[1] += (double)b[e] * u;                            // b, :99
-                }
-                v[2] += w[e]; // sumW over the same index set
+            for (int c = 0; c < C; c++) {
+                doq[c] = run[c] && !((mword[c] >> q) & 1ull);
+                anyq = anyq || doq[c];
             }
-            kl_block_sum<3>(v, red, par);
-            par ^= 1;
-            if (METHOD == 4) {
-                double tmp = v[0] / (v[2] + a.r0 * xq + a.r1 * (S - xq) + a.r2); // :142
-                const double c = (tmp - 1) * xq;                                  // :143
+            if (!anyq) { // no column of the block visits this coordinate: straight to the next row
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (row q has landed: its slots can be requested again)
+                issue_row(qn);
+                continue;
+            }
+            const f64x2 *Yq = (const f64x2 *)(a.Y + (size_t)q * a.ldy);
+            // (the LDS slot addresses are recomputed from this opaque copy in every step: as loop invariants the allocator kept one
+            //  address register per 64 KB window alive next to 160 state registers and spilled them -- and a scratch reload behind
+            //  the LDS-DMAs of pass B is a vmcnt(0), i.e. a wait for the whole row)
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            double xq[C];
 #pragma unroll
-                for (int e = 0; e < EPT; e++) y[e] = __builtin_fma(c, w[e], y[e]);
-                S += (tmp - 1) * xq; // :144
-                if (tid == 0) xs[q] = xq * tmp; // :145
-                tmp = 2 * fabs(tmp - 1) / (tmp + 1);
-                if (tmp > rel) rel = tmp;
-            } else {
-                double aa = v[0], bb = v[1] - v[2];          // b = dot(Aj, mu) - sumW(k), :99
-                aa += a.r0;                                  // :100
-                bb += aa * xq - a.r2 - a.r1 * (S - xq);      // :101
-                double tmp = bb / (aa + NNLM_TINY);          // :102
-                if (tmp < 0) tmp = 0;
-                if (tmp != xq) {
-                    const double d = tmp - xq;
+            for (int c = 0; c < C; c++) xq[c] = kl64_uni(xs[c * k + q]); // read BEFORE the barrier: thread 0 rewrites it after
+            double v[C][NV];
 #pragma unroll
-                    for (int e = 0; e < EPT; e++) y[e] = __builtin_fma(d, w[e], y[e]); // :106
-                    const double er = 2 * fabs(xq - tmp) / (tmp + xq + NNLM_TINY);
-                    if (er > rel) rel = er;
-                    S += tmp - xq;
-                    if (tid == 0) xs[q] = tmp;
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int u = 0; u < NV; u++) v[c][u] = 0.0;
+            f64x2 wreg[EREG > 0 ? EREG : 1];
+#pragma unroll
+            for (int e = ELDS; e < EPT2; e++) {
+                const int i2 = e * KL64_THREADS + tid;
+                wreg[e - ELDS] = (i2 < L2c) ? Yq[i2] : f64x2{0.0, 0.0};
+            }
+            // pass A.  The quotient is a chain of eight dependent fp64 instructions (~10 cycles each): four of them -- two (chunk,
+            // column) pairs x the two elements of a chunk -- are carried through the chain together, step by step, and the sums go to
+            // two partial accumulators per column (element 0 / element 1), or two wavefronts per SIMD spend the pass waiting on latency
+            // (first version: one quotient after the other into one accumulator, 10.9 ms per half-step at config 3 against a 3.7 ms
+            // issue bound).
+            double v2[C][NV]; // second partial accumulators (element 1 of every chunk)
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int u = 0; u < NV; u++) v2[c][u] = 0.0;
+            // chunk e of row q was requested e-th of ELDS LDS-DMAs (in order, during the previous step's pass B), the EREG plain loads
+            // above come behind them: a COUNTED wait lets pass A start on chunk 0 while the rest of the row is still on its way
+            // (one vmcnt(0) in front of the pass left the whole row fetch -- 160 KB per block from L2 -- exposed: 6.2 us per step)
+            auto wfetch = [&](auto ec) -> f64x2 {
+                constexpr int e = decltype(ec)::value;
+                if constexpr (e < ELDS) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ELDS - 1 - e + EREG) : "memory");
+                    return rowl[e * KL64_THREADS + tl];
+                } else
+                    return wreg[e - ELDS];
+            };
+            auto pair4 = [&](int ea, int ca, const f64x2 &wa, int eb, int cb, const f64x2 &wb_) {
+                double num[4], den[4], r[4], t[4], qv[4];
+                const double wv[4] = {wa[0], wa[1], wb_[0], wb_[1]};
+                const double bv[4] = {b[ca][ea][0], b[ca][ea][1], b[cb][eb][0], b[cb][eb][1]};
+                den[0] = y[ca][ea][0] + NNLM_TINY, den[1] = y[ca][ea][1] + NNLM_TINY, den[2] = y[cb][eb][0] + NNLM_TINY, den[3] = y[cb][eb][1] + NNLM_TINY;
+#pragma unroll
+                for (int i = 0; i < 4; i++) num[i] = (METHOD == 4) ? bv[i] : wv[i]; // Lee: Aj / (wh + eps), :141; SCD: mu = w / (Ajt + eps), :97
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[i] = __builtin_amdgcn_rcp(den[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) qv[i] = num[i] * r[i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], qv[i], num[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) qv[i] = __builtin_fma(t[i], r[i], qv[i]); // the correctly rounded quotient
+                if constexpr (METHOD == 4) {
+                    v[ca][0] = __builtin_fma(wv[0], qv[0], v[ca][0]);
+                    v2[ca][0] = __builtin_fma(wv[1], qv[1], v2[ca][0]);
+                    v[cb][0] = __builtin_fma(wv[2], qv[2], v[cb][0]);
+                    v2[cb][0] = __builtin_fma(wv[3], qv[3], v2[cb][0]);
+                } else {
+                    double bu[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bu[i] = bv[i] * qv[i];
+                    v[ca][0] = __builtin_fma(bu[0], qv[0], v[ca][0]), v[ca][1] += bu[0];     // a, :98; b, :99
+                    v2[ca][0] = __builtin_fma(bu[1], qv[1], v2[ca][0]), v2[ca][1] += bu[1];
+                    v[cb][0] = __builtin_fma(bu[2], qv[2], v[cb][0]), v[cb][1] += bu[2];
+                    v2[cb][0] = __builtin_fma(bu[3], qv[3], v2[cb][0]), v2[cb][1] += bu[3];
                 }
+            };
+            if constexpr (C == 1 && EPT2 >= 18) { // 160 state registers: one chunk (two chains) at a time, or the allocator spills
+                klq_for<0, EPT2>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const f64x2 w = wfetch(ec);
+                    double den[2] = {y[0][e][0] + NNLM_TINY, y[0][e][1] + NNLM_TINY}, num[2], r[2], t[2], qv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) num[i] = (METHOD == 4) ? b[0][e][i] : w[i];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) r[i] = __builtin_amdgcn_rcp(den[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) qv[i] = num[i] * r[i];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) t[i] = __builtin_fma(-den[i], qv[i], num[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) qv[i] = __builtin_fma(t[i], r[i], qv[i]);
+                    if constexpr (METHOD == 4) {
+                        v[0][0] = __builtin_fma(w[0], qv[0], v[0][0]);
+                        v2[0][0] = __builtin_fma(w[1], qv[1], v2[0][0]);
+                    } else {
+                        const double bu0 = b[0][e][0] * qv[0], bu1 = b[0][e][1] * qv[1];
+                        v[0][0] = __builtin_fma(bu0, qv[0], v[0][0]), v[0][1] += bu0;
+                        v2[0][0] = __builtin_fma(bu1, qv[1], v2[0][0]), v2[0][1] += bu1;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else if constexpr (C == 1) {
+                static_assert(C != 1 || EPT2 % 2 == 0, "C = 1 instantiations take the chunks in pairs");
+                klq_for<0, EPT2 / 2>([&](auto gc) {
+                    constexpr int e = 2 * decltype(gc)::value;
+                    const f64x2 wa = wfetch(std::integral_constant<int, e>{}), wb_ = wfetch(std::integral_constant<int, e + 1>{});
+                    pair4(e, 0, wa, e + 1, 0, wb_);
+                    __builtin_amdgcn_sched_barrier(0); // (keeps the compiler from hoisting later chunks' LDS reads: 160 state registers leave no room)
+                });
+            } else {
+                klq_for<0, EPT2>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const f64x2 w = wfetch(ec);
+#pragma unroll
+                    for (int c = 0; c < C; c += 2) pair4(e, c, w, e, c + 1, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int u = 0; u < NV; u++) v[c][u] += v2[c][u];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int u = 0; u < NV; u++) {
+                    const double t = wave_sum(v[c][u]);
+                    if (lane == 0) red[((par * C + c) * NV + u) * 8 + wave] = t;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // (LDS traffic only: __syncthreads() would also wait for nothing here, but keeps the habit of kl_tile_kernel)
+            asm volatile("" ::: "memory");
+            double coef[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                double sv[NV];
+#pragma unroll
+                for (int u = 0; u < NV; u++) {
+                    const double *rr = red + ((par * C + c) * NV + u) * 8;
+                    sv[u] = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+                }
+                const double sw = sws[c * k + q];
+                coef[c] = 0.0;
+                if (METHOD == 4) {
+                    double tmp = kl64_uni(sv[0] / (sw + a.r0 * xq[c] + a.r1 * (S[c] - xq[c]) + a.r2)); // :142
+                    if (doq[c]) {
+                        coef[c] = (tmp - 1) * xq[c];                                         // :143
+                        S[c] += (tmp - 1) * xq[c];                                           // :144
+                        if (tid == 0) xs[c * k + q] = xq[c] * tmp;                           // :145
+                        tmp = 2 * fabs(tmp - 1) / (tmp + 1);                                 // :146
+                        flag[c] = flag[c] || tmp > a.rel_tol;
+                    }
+                } else {
+                    double aa = sv[0], bb = sv[NV - 1] - sw; // b = dot(Aj, mu) - sumW(k), :99
+                    aa += a.r0;                              // :100
+                    bb += aa * xq[c] - a.r2 - a.r1 * (S[c] - xq[c]); // :101
+                    double tmp = kl64_uni(bb / (aa + NNLM_TINY)); // :102
+                    if (tmp < 0) tmp = 0;
+                    if (doq[c] && tmp != xq[c]) {
+                        coef[c] = tmp - xq[c];
+                        const double er = 2 * fabs(xq[c] - tmp) / (tmp + xq[c] + NNLM_TINY); // :107
+                        flag[c] = flag[c] || er > a.rel_tol;
+                        S[c] += tmp - xq[c];
+                        if (tid == 0) xs[c * k + q] = tmp;
+                    }
+                }
+            }
+            par ^= 1;
+            // pass B: y += coef * w (:106, :143); the row from LDS in groups of two chunks, each group's slots refilled with the
+            // next row as soon as it has been read back
+            constexpr int GB = (C == 1 && EPT2 >= 18) ? 1 : 2; // chunks per group (one where 160 state registers leave no room for two)
+#pragma unroll
+            for (int e0 = 0; e0 < EPT2; e0 += GB) {
+                f64x2 wb[GB];
+#pragma unroll
+                for (int u = 0; u < GB; u++) {
+                    const int e = e0 + u;
+                    if (e < EPT2) wb[u] = (e < ELDS) ? rowl[e * KL64_THREADS + tl] : wreg[e < ELDS ? 0 : e - ELDS];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < GB; u++)
+                    if (e0 + u < ELDS) issue_chunk(qn, e0 + u);
+#pragma unroll
+                for (int u = 0; u < GB; u++) {
+                    const int e = e0 + u;
+                    if (e < EPT2) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            y[c][e][0] = __builtin_fma(coef[c], wb[u][0], y[c][e][0]);
+                            y[c][e][1] = __builtin_fma(coef[c], wb[u][1], y[c][e][1]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads(); // xs[] written by thread 0 during this sweep is read by everyone in the next
-    }
-    __syncthreads();
-    if (tid < k) {
-        const double xv = xs[tid];
-        a.Xout[(size_t)tid * a.ldo + (col - a.ocol0)] = xv;
-        if (a.op_mode == 1) {
-            if (a.op_f64) ((double *)a.op)[(size_t)tid * a.op_ld + col] = xv;
-            else ((float *)a.op)[(size_t)tid * a.op_ld + col] = (float)xv;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + tid] = xv;
-            else ((float *)a.op)[(size_t)col * a.op_ld + tid] = (float)xv;
+        any = false;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if (run[c]) {
+                tdone[c]++;
+                run[c] = tdone[c] < a.max_iter && flag[c];
+            }
+            any = any || run[c];
         }
     }
-    if (tid == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the row requested for a sweep that did not follow
+    __syncthreads();
+    for (int e = tid; e < C * k; e += KL64_THREADS) {
+        const int c = e / k, q = e - c * k, col = col0 + c;
+        if (col < a.ncols) {
+            const double xv = xs[e];
+            a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
+            if (a.op_mode == 1) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
+        }
+    }
+    if (tid == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) tot += tdone[c];
+        if (tot) atomicAdd(a.sweeps, tot);
+    }
+}
+
+// What64[j][i] = sum_q W[q][i] H[q][j] in fp64, stored in the layout of A ([cols][lda], contraction index contiguous): the starting
+// state vectors of a strict-mode KL half-step (src/base_algorithms.cpp:81, :129) as one GEMM.  64 x 64 tile per block,
+// v_mfma_f64_16x16x4_f64 with M = column j, N = row i: a lane group stores 16 consecutive i (128 bytes).  For the W half-step the
+// caller swaps the roles of the factors (output rows = rows of A).
+__global__ __launch_bounds__(256) void wh_store64_kernel(const double *__restrict__ Wm, int ldw, const double *__restrict__ Hm, int ldh, int k4,
+                                                         double *__restrict__ What, size_t lda, int ni, int nj)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int ib = blockIdx.x * 64 + 32 * (wave & 1), jb = blockIdx.y * 64 + 32 * (wave >> 1);
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int z = 0; z < 2; z++) acc[x][z] = f64x4{0, 0, 0, 0};
+    for (int kq = lg; kq < k4; kq += 4) {
+        double wa[2], hb[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            wa[t] = Wm[(size_t)kq * ldw + ib + 16 * t + l15];
+            hb[t] = Hm[(size_t)kq * ldh + jb + 16 * t + l15];
+        }
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int z = 0; z < 2; z++) acc[x][z] = __builtin_amdgcn_mfma_f64_16x16x4f64(hb[z], wa[x], acc[x][z], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int i = ib + 16 * x + l15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = jb + 16 * z + lg + 4 * r;
+                if (i < ni && j < nj) What[(size_t)j * lda + i] = acc[x][z][r];
+            }
+        }
 }
 
 // ==================================================================================================================
@@ -488,7 +805,6 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             const double xv = xs[e];
             a.Xout[(size_t)q * a.ldo + (col - a.ocol0)] = xv;
             if (a.op_mode == 1) ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
-            else if (a.op_mode == 2) ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
     }
     if (wave == 0) {
@@ -649,9 +965,6 @@ __global__ __launch_bounds__(256) void kl_stream_kernel(const KlArgs a, int mw, 
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
             else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
-            else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
         }
     }
     if (tid == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);

@@ -8,12 +8,13 @@
 // Here:
 //   * the cross product needs nothing new: the resident A holds 0 at missing positions, so the dense
 //     A-streaming kernels (k_xprod.h) already sum over finite rows only;
-//   * na_gram_kernel (one 256-thread block per column) forms G_j in fp64 as either the direct sum over finite
-//     rows or  G_full - sum over missing rows  (complement), whichever touches fewer rows;  the rows of the
-//     fixed factor are gathered from a row-major copy ([p][KP], 512 B per row);
-//   * colsolve_ls_kernel (one wavefront per column, lane = coordinate) runs SCD / Lee with that column's own G.
-//     Lane r keeps column r of G_j in VGPRs (G is symmetric), the sequential coordinate index q is wave
-//     uniform, so G[q][r] is an indirect VGPR read (s_set_gpr_idx) and x[q], mu[q] are v_readlane.
+//   * the per-column Gram G_j is formed on the matrix cores, one wavefront per column, as either the direct sum over the
+//     finite rows or  G_full - sum over missing rows  (complement), whichever touches fewer rows, from row lists made once per
+//     matrix: na_gram_f16_kernel (fp32-operand mode: split-fp16 rows, v_mfma_f32_16x16x32_f16) / na_gram_lds_kernel<double>
+//     (strict mode: fp64 rows gathered by LDS-DMA, v_mfma_f64_16x16x4_f64);
+//   * one wavefront per column, lane = coordinate, solves with that column's own G: colsolve_fast_kernel (SCD, fp32-operand
+//     mode: rows of G divided by their diagonal), colsolve_strict_kernel (SCD in the reference's arithmetic), colsolve_ls_kernel
+//     (Lee's multiplicative updates: lane r keeps column r of G_j in VGPRs, G[q][r] is an indirect VGPR read, x[q] a v_readlane).
 //
 // The missing-entry index sets are 1-bit-per-entry masks built by the prep pass (exact, integer):
 //   miss  [mpad][npad/32]  bit (i%32) of word [j][i/32]   -- used by the H half-step (column j of A)
@@ -46,93 +47,6 @@ __global__ __launch_bounds__(256) void factor_rows_kernel(const double *__restri
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncols) return;
     for (int q = 0; q < KP; q++) Yrow[(size_t)c * KP + q] = (T)Y[(size_t)q * ld + c];
-}
-
-// Per-column Gram.  bits: this column's missing mask over the contraction index (p bits, `words` words per
-// column); Yrow [p][KP]; Gfull [KP][KP]; Gcols [ncols][KP][KP].
-#define NAG_BATCH 32
-template <int NKQ>
-__global__ __launch_bounds__(256) void na_gram_kernel(const uint32_t *__restrict__ bits_all, int words, int p,
-                                                      const double *__restrict__ Yrow, const double *__restrict__ Gfull,
-                                                      double *__restrict__ Gcols, int col0 = 0)
-{
-    constexpr int KP = 16 * NKQ;
-    constexpr int NB = KP / 4; // 4x4 register blocks per side
-    __shared__ double rows[NAG_BATCH][KP];
-    __shared__ int sel[256];
-    __shared__ int nsel_s, cnt_s;
-    __shared__ int wcnt[4];
-    const int col = col0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t *bits = bits_all + (size_t)col * words;
-
-    // number of missing rows in this column
-    if (tid == 0) cnt_s = 0;
-    __syncthreads();
-    int c = 0;
-    for (int w = tid; w < (p + 31) / 32; w += 256) {
-        uint32_t v = bits[w];
-        if ((w + 1) * 32 > p) v &= (p & 31) ? ((1u << (p & 31)) - 1u) : 0xFFFFFFFFu;
-        c += __popc(v);
-    }
-    c = (int)wave_sum_ll(c);
-    if (lane == 0 && c) atomicAdd(&cnt_s, c);
-    __syncthreads();
-    const int nmiss = cnt_s;
-    const bool complement = nmiss * 2 <= p; // sum over the missing rows and subtract from the full Gram
-    const uint32_t want = complement ? 1u : 0u;
-
-    const int bq = tid / NB, br = tid % NB;
-    const bool owner = tid < NB * NB;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-
-    for (int base = 0; base < p; base += 256) {
-        // compact the selected row indices of this 256-candidate chunk (order preserved)
-        const int i = base + tid;
-        bool take = false;
-        if (i < p) take = ((bits[i >> 5] >> (i & 31)) & 1u) == want;
-        const unsigned long long bal = __ballot(take);
-        if (lane == 0) wcnt[wave] = __popcll(bal);
-        __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; w++) off += wcnt[w];
-        if (take) sel[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        if (tid == 0) nsel_s = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-        const int nsel = nsel_s;
-        for (int b0 = 0; b0 < nsel; b0 += NAG_BATCH) {
-            const int nb = (nsel - b0 < NAG_BATCH) ? nsel - b0 : NAG_BATCH;
-            for (int e = tid; e < nb * KP; e += 256) rows[e / KP][e % KP] = Yrow[(size_t)sel[b0 + e / KP] * KP + (e % KP)];
-            __syncthreads();
-            if (owner)
-                for (int r = 0; r < nb; r++) {
-                    double a4[4], b4[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        a4[t] = rows[r][4 * bq + t];
-                        b4[t] = rows[r][4 * br + t];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; a++)
-#pragma unroll
-                        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_fma(a4[a], b4[b], acc[a][b]);
-                }
-            __syncthreads();
-        }
-    }
-    if (owner) {
-        double *out = Gcols + (size_t)col * KP * KP;
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int idx = (4 * bq + a) * KP + 4 * br + b;
-                out[idx] = complement ? Gfull[idx] - acc[a][b] : acc[a][b];
-            }
-    }
 }
 
 // One wavefront per column, lane = coordinate (k <= 64).  a.Graw is either one shared Gram (g_stride = 0) or the
@@ -249,23 +163,18 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
             else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
-            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
         }
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Per-column Gram on the fp64 matrix cores over PRECOMPUTED row lists.
+// Per-column Grams over PRECOMPUTED row lists.
 // The missing pattern of A does not change between iterations, so the rows a column's Gram sums over (the missing rows
 // when at most half are missing -- G_j = G_full - sum, otherwise the present rows) are compacted once per matrix into
-// CSR lists (na_count_kernel / na_fill_kernel); na_gram_mfma_kernel then runs one wavefront per column:
-// four listed rows per step, lane (l15, lg) loads Yrow[row_lg][16t + l15] for each 16-wide tile t (128-byte segments of
-// four rows), and one v_mfma_f64_16x16x4_f64 per upper tile pair accumulates  sum_r y_r y_r^T  (the same register is
-// the A operand of tile a and the B operand of tile b).  2 k^2 len flops per column at the fp64 MFMA rate instead of the
-// 4x4-register-block VALU loop of na_gram_kernel (which also re-compacts the index list every launch).
+// CSR lists (na_count_kernel / na_fill_kernel); the Gram kernels below then run one wavefront per column over its list:
+// one MFMA per upper tile pair accumulates  sum_r y_r y_r^T  (the same register is the A operand of tile a and the B
+// operand of tile b).
 __global__ __launch_bounds__(256) void na_count_kernel(const uint32_t *__restrict__ bits_all, int words, int p, int ncols, uint32_t *__restrict__ cnt)
 {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -309,103 +218,11 @@ __global__ __launch_bounds__(256) void na_fill_kernel(const uint32_t *__restrict
     }
 }
 
-// T = float (fp32-operand mode): the listed rows enter v_mfma_f32_16x16x4_f32 rounded to fp32 (twice the fp64 rate, half the
-// gather bytes), fp32 partial sums are folded into fp64 every 256 rows as in the cross products; the correction
-// sum_missing w w^T is ~the missing fraction of G, so G_j keeps ~1e-8 relative accuracy.  T = double: the strict mode.
-template <typename T, int NKQ>
-__global__ __launch_bounds__(256) void na_gram_mfma_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
-                                                           const T *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
-                                                           int ncols, int col0 = 0)
-{
-    using M = Mfma<T>;
-    using acc_t = typename M::acc_t;
-    constexpr int KP = 16 * NKQ;
-    constexpr int NP = NKQ * (NKQ + 1) / 2;
-    constexpr bool F32 = sizeof(T) == 4;
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
-    const int col = col0 + blockIdx.x * 4 + (threadIdx.x >> 6); // columns col0 .. ncols-1
-    if (col >= ncols) return; // whole wave
-    const uint32_t mt = meta[col];
-    const int len = (int)(mt & 0x7FFFFFFFu);
-    const bool complement = (mt >> 31) != 0;
-    const int *rows = idx + ptr[col];
-
-    acc_t acc[NP];
-    f64x4 acc64[F32 ? NP : 1];
-#pragma unroll
-    for (int i = 0; i < NP; i++) acc[i] = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < (F32 ? NP : 1); i++) acc64[i] = f64x4{0, 0, 0, 0};
-    // Tile t, position l15 stands for coordinate NKQ * l15 + t (not 16 t + l15): a lane's NKQ operands are then NKQ CONSECUTIVE
-    // entries of the listed row -- one 16-byte load for NKQ = 4 floats instead of four 4-byte loads 64 bytes apart -- and the Gram
-    // comes out with rows and columns permuted the same way, undone in the index arithmetic of the final store.
-    // Two groups of four rows are in flight ahead of the one being multiplied (the gathers are L2 / MALL latency).
-    T x[NKQ], xn[NKQ], xnn[NKQ];
-    auto load = [&](int g, T (&dst)[NKQ]) {
-        const int r = 4 * g + lg;
-        const int row = (r < len) ? rows[r] : -1;
-        if (row >= 0) {
-            constexpr size_t AL = (NKQ == 3) ? sizeof(T) : NKQ * sizeof(T); // (NKQ = 3: no power-of-two vector)
-            const T *src = (const T *)__builtin_assume_aligned(Yrow + (size_t)row * KP + NKQ * l15, AL);
-            __builtin_memcpy(dst, src, sizeof(T) * NKQ);
-        } else {
-#pragma unroll
-            for (int t = 0; t < NKQ; t++) dst[t] = (T)0;
-        }
-    };
-    const int ng = (len + 3) / 4;
-    if (ng > 0) load(0, x);
-    if (ng > 1) load(1, xn);
-    int since = 0;
-    for (int g = 0; g < ng; g++) {
-        if (g + 2 < ng) load(g + 2, xnn);
-        int pi = 0;
-#pragma unroll
-        for (int a = 0; a < NKQ; a++)
-#pragma unroll
-            for (int b = a; b < NKQ; b++, pi++) acc[pi] = M::mma(x[a], x[b], acc[pi]);
-#pragma unroll
-        for (int t = 0; t < NKQ; t++) {
-            x[t] = xn[t];
-            xn[t] = xnn[t];
-        }
-        if constexpr (F32) {
-            if (++since == 64) { // 256 rows
-                since = 0;
-#pragma unroll
-                for (int i = 0; i < NP; i++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc64[i][r] += (double)acc[i][r];
-                    acc[i] = acc_t{0, 0, 0, 0};
-                }
-            }
-        }
-    }
-    // C/D layout: reg r -> tile row M::row_of(lane, r), tile column l15, i.e. coordinates (NKQ row + a, NKQ l15 + b); both
-    // triangles of the symmetric result
-    double *out = Gcols + (size_t)col * KP * KP;
-    int pi = 0;
-#pragma unroll
-    for (int a = 0; a < NKQ; a++)
-#pragma unroll
-        for (int b = a; b < NKQ; b++, pi++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = NKQ * M::row_of(lane, r) + a, j = NKQ * l15 + b;
-                double sum;
-                if constexpr (F32) sum = acc64[pi][r] + (double)acc[pi][r];
-                else sum = acc[pi][r];
-                const double v = complement ? Gfull[i * KP + j] - sum : sum;
-                out[i * KP + j] = v;
-                if (a != b) out[j * KP + i] = v;
-            }
-}
-
-// Per-column Gram (T = float: fp32-operand mode with NNLM_NA_GRAM_F16=0; T = double: the strict mode) with the listed rows gathered by
+// Per-column Gram of the strict mode (instantiated with T = double) with the listed rows gathered by
 // LDS-DMA (global_load_lds_dwordx4): a group of four rows is ONE instruction per wavefront (two for fp64 rows of 64) (lane = 16-byte chunk: row lane / (KP/4), chunk lane % (KP/4)) that lands in one of four stage buffers
 // of the wavefront and occupies no VGPR.  Three groups are in flight while one is multiplied (s_waitcnt vmcnt(3), written by hand:
 // the instruction is issued as inline asm, so the compiler's wait-count pass neither sees it nor serialises the LDS reads behind
-// it).  Register-destination gathers (na_gram_mfma_kernel) leave the depth of the pipeline to the register
+// it).  Register-destination gathers leave the depth of the pipeline to the register
 // allocator: a rotated copy or a branch around a gather ends in "wait for everything".  The four row indices of a group are
 // scalar loads (lgkmcnt), two groups ahead.  Operands come from LDS in the natural layout (tile t, position l15 = coordinate
 // 16 t + l15).
@@ -878,9 +695,6 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
             else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
-            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
         }
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
@@ -988,9 +802,6 @@ __global__ __launch_bounds__(256) void colsolve_strict_kernel(const SweepArgs a,
         if (a.op_mode == 1) {
             if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
             else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
-        } else if (a.op_mode == 2) {
-            if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + lane] = x;
-            else ((float *)a.op)[(size_t)col * a.op_ld + lane] = (float)x;
         }
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);

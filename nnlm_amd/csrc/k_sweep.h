@@ -52,7 +52,7 @@ struct SweepArgs {
     unsigned max_iter;
     double rel_tol;
     void *op;           // GEMM-operand copy of the updated factor
-    int op_mode;        // 0: none, 1: [KP][op_ld] (same layout as X), 2: [col][op_ld] (kq fastest)
+    int op_mode;        // 0: none, 1: [KP][op_ld] (same layout as X)
     int op_ld;
     int op_f64;         // element type of op: 0 float, 1 double
     unsigned long long *sweeps; // += sum of per-column sweep counts
@@ -315,9 +315,6 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                     if (a.op_mode == 1) {
                         if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + col] = xv;
                         else ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
-                    } else if (a.op_mode == 2) {
-                        if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
-                        else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
                     }
                 }
             }

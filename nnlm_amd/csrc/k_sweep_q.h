@@ -328,16 +328,6 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
             }
         }
     }
-    if (a.op_mode == 2) { // [col][op_ld], kq fastest: consecutive threads write consecutive kq of one column
-        for (int e = tid; e < SWEEPQ_COLS * KP; e += SWEEPQ_THREADS) {
-            const int c = e / KP, q = e % KP, ecol = col_base + c;
-            if (q < k && ecol < a.ncols) {
-                const double xv = xl[c * XS + q];
-                if (a.op_f64) ((double *)a.op)[(size_t)ecol * a.op_ld + q] = xv;
-                else ((float *)a.op)[(size_t)ecol * a.op_ld + q] = (float)xv;
-            }
-        }
-    }
     if (a.maxbits) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));

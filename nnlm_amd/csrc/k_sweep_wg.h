@@ -330,16 +330,6 @@ __global__ __launch_bounds__(SWEEP_WG_THREADS) void sweep_scd_wg_kernel(const Sw
             }
         }
     }
-    if (a.op_mode == 2) { // [col][op_ld], kq fastest: consecutive threads write consecutive kq of one column
-        for (int e = tid; e < SWEEP_WG_COLS * KP; e += SWEEP_WG_THREADS) {
-            const int c = e / KP, q = e % KP, col = col_base + c;
-            if (q < k && col < a.ncols) {
-                const double xv = xl[c * XS + q];
-                if (a.op_f64) ((double *)a.op)[(size_t)col * a.op_ld + q] = xv;
-                else ((float *)a.op)[(size_t)col * a.op_ld + q] = (float)xv;
-            }
-        }
-    }
 #ifdef SWEEP_WG_TIMING
     if (a.op && blockIdx.x == 0 && lane == 0 && (wave == CW || wave == 1)) {
         unsigned long long *dbg = (unsigned long long *)a.op; // harness: [role][work, wait]

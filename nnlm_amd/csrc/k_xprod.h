@@ -1,15 +1,15 @@
-// k_xprod.h -- the two A-streaming skinny GEMMs of a half-step.
+// k_xprod.h -- the A-streaming skinny GEMM of a half-step in the strict fp64 mode (the fp32-operand mode runs k_xprod16.h).
 //
 // Reference: the per-column gemv `Wt * A.col(j)` inside update()'s OpenMP loop
 // (src/update_with_missing.cpp:39,45) and, for the W half-step, the same on the materialised
-// `A.t()` (src/nnmf.cpp:131).  Here both are one pass over the SAME resident column-major A:
+// `A.t()` (src/nnmf.cpp:131 -- in EVERY iteration; here the transposed copy is made once per matrix):
 //
-//   xprod_tn : C[kq, j] = sum_i Y[kq, i] * A[i, j]   (H half-step, Y = W^T, contraction contiguous)
-//   xprod_nt : C[kq, i] = sum_j Y[kq, j] * A[i, j]   (W half-step, Y = H,   contraction strided)
+//   xprod_tn : C[kq, j] = sum_i Y[kq, i] * A[i, j]   (contraction index contiguous in both operands)
 //
-// so A.t() is never formed.  Both are split-K: block (x, s) contracts stage range s of tile x and
-// writes an fp64 slab Cx[s][KP][ldc]; the consumer (sweep kernel, or the slab reduce ahead of the
-// RCCL all-reduce) sums the slabs in a fixed order -> deterministic.
+// H half-step: A as stored, Y = W^T; W half-step: the transposed copy of A, Y = H.  (Round 1-2 ran the W half-step on
+// the untransposed matrix with a strided-contraction "NT" kernel: 1.0 ms against 0.47 ms for the same bytes.)
+// Split-K: block (x, s) contracts stage range s of tile x and writes an fp64 slab Cx[s][KP][ldc]; the consumer (sweep
+// kernel, or the slab reduce ahead of the RCCL all-reduce) sums the slabs in a fixed order -> deterministic.
 //
 // MFMA: 16x16x4 (f32 or f64 inputs), one operand element per lane.  Tiles of A and of the factor
 // go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a ring of XPROD_NBUF stage
@@ -17,7 +17,7 @@
 // `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the queue).  A block is 8
 // wavefronts = 2 per SIMD, each owning one 16-row M-tile of the stage: while one wave of a SIMD issues
 // its LDS fragment reads / DMA, the other keeps the matrix pipe busy.  Fragments leave LDS as
-// ds_read_b128 (TN) / ds_read_b64 (NT A side).  In f32 mode partial sums are kept in f32 for at most
+// ds_read_b128.  With T = float partial sums are kept in f32 for at most
 // XPROD_FLUSH_ELEMS contraction elements and then folded into fp64 accumulators (SURVEY.md section 7
 // "precision ladder").
 //
@@ -30,15 +30,10 @@
 #define XPROD_FLUSH_ELEMS 256
 #define XPROD_ROWB 256            // bytes per LDS row of the TN images (one 16-lane group per row)
 #define XPROD_TN_BJ 128           // columns j per block (TN) = 8 waves x 16
-#define XPROD_NT_ROWS 32          // contraction rows j per stage (NT)
-#define XPROD_A_IMG_BYTES 32768   // A image per stage, both kernels
+#define XPROD_A_IMG_BYTES 32768   // A image per stage
 #define XPROD_NBUF 3              // LDS stage buffers: one being consumed, two in flight from HBM
 
 __host__ __device__ static inline int xprod_tn_lds_bytes(int KP) { return XPROD_NBUF * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB); }
-template <typename T> __host__ __device__ static inline int xprod_nt_lds_bytes(int KP)
-{
-    return XPROD_NBUF * (XPROD_A_IMG_BYTES + XPROD_NT_ROWS * KP * (int)sizeof(T));
-}
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: waits until at most n of this wavefront's vector-memory
 // operations are outstanding.  global_load_lds completes in issue order, so "n = loads of the newest stage" means
@@ -240,182 +235,5 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
             v += __shfl_xor(v, 32, 64);
             if (lg == 0) out[(size_t)(16 * NKQ + u) * ldc + j0 + 16 * wave + l15] = v;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// NT: contraction along j (stride lda in memory).
-//   A      [mpad][lda], Yop [mpad][KP] (row j, kq fastest), Cx [S][KP][ldc] fp64, ldc >= npad
-//   grid   (npad/BI, S) with BI = 64*EPV output rows i per block (256 f32 / 128 f64)
-//   stage  = 32 contraction rows j; an image row is 1 KiB of one column of A = one
-//            global_load_lds instruction.  Fragment reads walk 8-byte slots inside a row
-//            (16 lanes) and 4 consecutive rows (lane groups).
-// Wave w owns rows i [w*BI/8, (w+1)*BI/8).  Lane (l&15) of an A fragment holds MT = EPV/2 consecutive i
-// (one per M-tile e); lane (l&15) of a factor fragment holds NKQ consecutive kq (one per N-tile t):
-// the MFMA row/column <-> (i, kq) map is a permutation that is undone in the epilogue.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int NKQ, int KT = 0>
-__global__ __launch_bounds__(XPROD_THREADS) void xprod_nt_kernel(const T *__restrict__ A, int lda,
-                                                                 const T *__restrict__ Yop,
-                                                                 double *__restrict__ Cx, int ldc, size_t slab_stride,
-                                                                 int stage_begin, int stage_end, int stages_per_split)
-{
-    using M = Mfma<T>;
-    using acc_t = typename M::acc_t;
-    constexpr int EPV = M::EPV;
-    constexpr int MT = EPV / 2;                       // M-tiles per wave (8-byte A fragment)
-    constexpr int KP = 16 * (NKQ + (KT > 0 ? 1 : 0));  // entries of a factor row (= the handle's KP)
-    constexpr int BI = 64 * EPV;
-    constexpr int YROW = KP * (int)sizeof(T);          // bytes of one factor row
-    constexpr int YIMG = XPROD_NT_ROWS * YROW;         // bytes of the factor image (multiple of 1 KiB)
-    constexpr int BUF = XPROD_A_IMG_BYTES + YIMG;
-    constexpr int FL = XPROD_FLUSH_ELEMS / XPROD_NT_ROWS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int i0 = blockIdx.x * BI;
-    int st0 = stage_begin + blockIdx.y * stages_per_split;
-    int st1 = st0 + stages_per_split;
-    if (st1 > stage_end) st1 = stage_end;
-
-    acc_t acc[MT][NKQ];
-    f64x4 acc64[MT][NKQ];
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < NKQ; b++) {
-            acc[a][b] = acc_t{0, 0, 0, 0};
-            acc64[a][b] = f64x4{0, 0, 0, 0};
-        }
-    T tacc[MT][KT > 0 ? KT : 1];
-    double tacc64[MT][KT > 0 ? KT : 1];
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int u = 0; u < (KT > 0 ? KT : 1); u++) {
-            tacc[a][u] = (T)0;
-            tacc64[a][u] = 0.0;
-        }
-
-    auto issue = [&](int st, unsigned char *buf) {
-        const size_t jb = (size_t)st * XPROD_NT_ROWS;
-#pragma unroll
-        for (int t = wave; t < XPROD_NT_ROWS; t += XPROD_WAVES)
-            glds16(A + (jb + t) * lda + i0 + lane * EPV, buf + t * 1024);
-        const unsigned char *ysrc = (const unsigned char *)(Yop + jb * KP);
-#pragma unroll
-        for (int u = wave; u < YIMG / 1024; u += XPROD_WAVES)
-            glds16(ysrc + u * 1024 + lane * 16, buf + XPROD_A_IMG_BYTES + u * 1024);
-    };
-
-    // loads THIS wavefront issues per stage: 4 rows of A + its share of the YIMG/1024 factor-image instructions
-    const int per_stage = XPROD_NT_ROWS / XPROD_WAVES + strided_count(wave, YIMG / 1024);
-    if (st0 < st1) issue(st0, smem);
-    if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
-    int since_flush = 0;
-    for (int st = st0; st < st1; ++st) {
-        unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
-        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
-        __builtin_amdgcn_s_barrier();
-        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
-#pragma unroll
-        for (int kk = 0; kk < XPROD_NT_ROWS / 4; kk++) {
-            const int row = lg + 4 * kk;
-            T a[MT], b[NKQ];
-            {
-                const double raw = *(const double *)(buf + row * 1024 + wave * 128 + l15 * 8);
-                __builtin_memcpy(a, &raw, 8);
-            }
-            {
-                const unsigned char *p = buf + XPROD_A_IMG_BYTES + row * YROW + l15 * (NKQ * (int)sizeof(T));
-                if constexpr (NKQ * sizeof(T) == 16) {
-                    const f32x4 raw = *(const f32x4 *)p;
-                    __builtin_memcpy(b, &raw, 16);
-                } else if constexpr (NKQ * sizeof(T) == 32) {
-                    const f32x4 r0 = *(const f32x4 *)p, r1 = *(const f32x4 *)(p + 16);
-                    __builtin_memcpy(b, &r0, 16);
-                    __builtin_memcpy((unsigned char *)b + 16, &r1, 16);
-                } else if constexpr (NKQ * sizeof(T) == 8) {
-                    const double raw = *(const double *)p;
-                    __builtin_memcpy(b, &raw, 8);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NKQ; t++) b[t] = ((const T *)p)[t];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < MT; e++)
-#pragma unroll
-                for (int t = 0; t < NKQ; t++) acc[e][t] = M::mma(a[e], b[t], acc[e][t]);
-            if constexpr (KT > 0) { // tail entries 16*NKQ + u of the factor row: the same address for all 16 lanes of a group
-                const T *hp = (const T *)(buf + XPROD_A_IMG_BYTES + row * YROW) + 16 * NKQ;
-#pragma unroll
-                for (int u = 0; u < KT; u++) {
-                    const T hv = hp[u];
-                    if constexpr (MT == 2) {
-                        using v2_t = typename XpVec2<T>::type;
-                        const v2_t t = __builtin_elementwise_fma(v2_t{a[0], a[1]}, v2_t{hv, hv}, v2_t{tacc[0][u], tacc[1][u]});
-                        tacc[0][u] = t[0];
-                        tacc[1][u] = t[1];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < MT; e++) tacc[e][u] = fma_t(a[e], hv, tacc[e][u]);
-                    }
-                }
-            }
-        }
-        if constexpr (sizeof(T) == 4) {
-            if (++since_flush == FL) {
-                since_flush = 0;
-#pragma unroll
-                for (int a = 0; a < MT; a++)
-#pragma unroll
-                    for (int b = 0; b < NKQ; b++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc64[a][b][r] += (double)acc[a][b][r];
-                        acc[a][b] = acc_t{0, 0, 0, 0};
-                    }
-                if constexpr (KT > 0) {
-#pragma unroll
-                    for (int a = 0; a < MT; a++)
-#pragma unroll
-                        for (int u = 0; u < KT; u++) {
-                            tacc64[a][u] += (double)tacc[a][u];
-                            tacc[a][u] = (T)0;
-                        }
-                }
-            }
-        }
-    }
-    // epilogue: tile (e, t): M index -> i = i0 + wave*16*MT + MT*M + e ; N index (l&15) -> kq = NKQ*(l&15) + t.
-    // For a fixed (t, r) the MT tiles of a lane are MT consecutive i.
-    double *out = Cx + (size_t)blockIdx.y * slab_stride;
-#pragma unroll
-    for (int t = 0; t < NKQ; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int kq = NKQ * l15 + t;
-            const int i = i0 + wave * 16 * MT + MT * M::row_of(lane, r);
-            double vv[MT];
-#pragma unroll
-            for (int e = 0; e < MT; e++) {
-                if constexpr (sizeof(T) == 4) vv[e] = acc64[e][t][r] + (double)acc[e][t][r];
-                else vv[e] = acc[e][t][r];
-            }
-            double *dst = out + (size_t)kq * ldc + i;
-            if constexpr (MT == 2) *(f64x2 *)dst = f64x2{vv[0], vv[1]};
-            else dst[0] = vv[0];
-        }
-    if constexpr (KT > 0) { // lane (l15, lg): rows i = i0 + wave*16*MT + MT*l15 + e, partial over contraction rows = lg mod 4
-#pragma unroll
-        for (int u = 0; u < KT; u++)
-#pragma unroll
-            for (int e = 0; e < MT; e++) {
-                double v = tacc64[e][u] + (double)tacc[e][u];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (lg == 0) out[(size_t)(16 * NKQ + u) * ldc + i0 + wave * 16 * MT + MT * l15 + e] = v;
-            }
     }
 }

@@ -36,8 +36,9 @@
 
 static thread_local std::string g_last_error;
 
-enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_COUNT };
-static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors"};
+enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_XPROD_W_ERR, P_COUNT };
+// ("xprod_w_err": W half-step cross products that also evaluate the error sums -- the fused launches have a scope of their own)
+static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors", "xprod_w_err"};
 
 struct ProfRec {
     int id;
@@ -48,9 +49,8 @@ struct nnlm_handle {
     int device = 0;
     int prec = NNLM_PREC_F32;
     hipStream_t stream = nullptr;   // main: cross products, solvers
-    hipStream_t stream_g = nullptr; // Gram of the fixed factor, concurrent with the A-streaming cross product
     hipStream_t stream_e = nullptr; // error block, concurrent with the (speculative) next W half-step
-    hipEvent_t ev_factor = nullptr, ev_gram = nullptr, ev_hdone = nullptr, ev_err = nullptr, ev_xdone = nullptr;
+    hipEvent_t ev_hdone = nullptr, ev_err = nullptr, ev_xdone = nullptr;
     std::string err;
 
     // problem
@@ -67,7 +67,7 @@ struct nnlm_handle {
     // factors
     int k = 0, NKQ = 0, KP = 0, KP8 = 0;
     double *W64 = nullptr, *H64 = nullptr;        // [KP][npad], [KP][mpad]  (W64 = W64b[wcur])
-    void *Wop = nullptr, *Hop = nullptr;          // T [KP][npad] (aliases W64 in f64 mode), T [mpad][KP]  (Wop = Wopb[wcur])
+    void *Wop = nullptr;                          // T [KP][npad] (aliases W64 in f64 mode)  (Wop = Wopb[wcur])
     double *W64b[2] = {nullptr, nullptr};         // W is double buffered: every W half-step writes the other buffer, so a
     void *Wopb[2] = {nullptr, nullptr};           // speculative half-step can be dropped and the error block can read W_i
     int wcur = 0;
@@ -87,7 +87,7 @@ struct nnlm_handle {
     double *gslabs = nullptr, *Graw = nullptr; // Graw = head of red
     double *red = nullptr;               // [KP*KP | KP*max(npad,mpad)]: the buffer one all-reduce sums
     // NA path: per orientation (0: rows of A for the W half-step, 1: columns for the H half-step) the CSR lists of the rows a
-    // column's Gram sums over (k_missing.h, na_gram_mfma_kernel); built on first use, they live as long as the matrix
+    // column's Gram sums over (k_missing.h); built on first use, they live as long as the matrix
     uint32_t *na_ptr[2] = {nullptr, nullptr}, *na_meta[2] = {nullptr, nullptr};
     int *na_idx[2] = {nullptr, nullptr};
     double *Yrow = nullptr;              // [max(npad,mpad)][KP] row-major copy of the fixed factor (NA path)
@@ -125,6 +125,7 @@ struct nnlm_handle {
     bool pack_ready = false;     // sweepq_img already produced for this half-step (the one-stream dense flow packs it ahead of the cross product)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
     float *What = nullptr;       // [mpad][npad] fp32 W^T H: starting state vectors of a KL half-step (wh_store_kernel), on first use
+    double *What64 = nullptr;    // the same in fp64 for the strict mode (wh_store64_kernel)
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
     bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
     int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
@@ -155,16 +156,8 @@ static int fail(nnlm_handle *h, int code, const char *fmt, ...)
         if (e__ != hipSuccess) return fail(h, NNLM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
-// split-fp16 cross products: the default of the F32 mode; NNLM_XPROD=f32 keeps the fp32 MFMA kernels
-static bool x16_enabled(int precision)
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NNLM_XPROD");
-        v = (e && strcmp(e, "f32") == 0) ? 0 : 1;
-    }
-    return precision == NNLM_PREC_F32 && v == 1;
-}
+// split-fp16 cross products (k_xprod16.h): THE cross products of the F32 mode
+static bool x16_enabled(int precision) { return precision == NNLM_PREC_F32; }
 
 static size_t esize(const nnlm_handle *h) { return h->prec == NNLM_PREC_F64 ? 8 : 4; }
 
@@ -197,7 +190,6 @@ struct ProfScope {
 static void sync_all(nnlm_handle *h)
 {
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->stream_g) hipStreamSynchronize(h->stream_g);
     if (h->stream_e) hipStreamSynchronize(h->stream_e);
 }
 
@@ -280,10 +272,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     h->device = device;
     h->prec = precision;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream_g, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_factor, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gram, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_hdone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_err, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_xdone, hipEventDisableTiming) != hipSuccess) {
@@ -318,14 +307,15 @@ static void free_factors(nnlm_handle *h)
     }
     h->wcur = 0;
     hipFree(h->H64);
-    hipFree(h->Hop);
     hipFree(h->Hkq);
     h->Hkq = nullptr;
     hipFree(h->Wmask);
     hipFree(h->Hmask);
     hipFree(h->Cx);
     hipFree(h->What);
+    hipFree(h->What64);
     h->What = nullptr;
+    h->What64 = nullptr;
     hipFree(h->klsw);
     hipFree(h->klsw_cols);
     hipFree(h->klst);
@@ -349,7 +339,7 @@ static void free_factors(nnlm_handle *h)
     hipFree(h->Gcols);
     h->red = h->Yrow = h->Gcols = nullptr;
     h->W64 = h->H64 = nullptr;
-    h->Wop = h->Hop = nullptr;
+    h->Wop = nullptr;
     h->Wmask = h->Hmask = nullptr;
     h->Cx = h->gslabs = h->Graw = nullptr;
     h->k = 0;
@@ -400,12 +390,9 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipFree(h->sweepq_img);
     hipFree(h->maxbits);
     hipFree(h->scal_exp);
-    if (h->ev_factor) hipEventDestroy(h->ev_factor);
-    if (h->ev_gram) hipEventDestroy(h->ev_gram);
     if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
     if (h->ev_err) hipEventDestroy(h->ev_err);
     if (h->ev_xdone) hipEventDestroy(h->ev_xdone);
-    if (h->stream_g) hipStreamDestroy(h->stream_g);
     if (h->stream_e) hipStreamDestroy(h->stream_e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -520,7 +507,7 @@ extern "C" int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_
 static int split_plan(int tiles_x, int stages, int *S, int *sps)
 {
     const int cus = 256;
-    static int smax = getenv("NNLM_SPLIT_MAX") ? atoi(getenv("NNLM_SPLIT_MAX")) : 16;
+    const int smax = 16;
     int best_s = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= smax; s++) {
@@ -547,7 +534,9 @@ struct HalfPlan {
     int col_off = 0; // first column of the factor being solved that this launch covers (column shards of the multi-GPU NA path)
 };
 
-// which = 1: H half-step (TN, contraction over i); which = 0: W half-step (NT, contraction over j)
+// which = 1: H half-step (contraction over i, A as stored); which = 0: W half-step (contraction over j: the same "TN" kernels on
+// the transposed copy of A -- A16T in the split-fp16 mode, AT otherwise -- made once per matrix; the reference transposes A in
+// EVERY iteration, src/nnmf.cpp:131)
 static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
 {
     HalfPlan p;
@@ -559,13 +548,9 @@ static HalfPlan plan_half(const nnlm_handle *h, int which, int rank, int nranks)
     } else if (h->x16) { // split-fp16: the TN kernel on the transposed copy, tiles of 128 rows of A, stages of 64 columns
         stages_total = h->mpad / 64;
         tiles_x = h->npad / XPROD_TN_BJ;
-    } else if (h->k > NNLM_KQ_MAX) { // rank > 64: the TN kernel on the transposed copy AT (launch_xprod_generic)
+    } else { // strict mode (and rank > 64 without split copies): the TN kernel on the transposed copy AT
         stages_total = h->mpad / (XPROD_ROWB / (int)esize(h));
         tiles_x = h->npad / XPROD_TN_BJ;
-    } else {
-        stages_total = h->mpad / XPROD_NT_ROWS;
-        const int BI = 64 * (16 / (int)esize(h));
-        tiles_x = h->npad / BI;
     }
     // this rank's slab of the contraction
     const int per_rank = (stages_total + nranks - 1) / nranks;
@@ -585,8 +570,7 @@ static int stage_elems(const nnlm_handle *h, int which)
 {
     if (which == 1) return XPROD_ROWB / (int)esize(h);
     if (h->x16) return 64;
-    if (h->k > NNLM_KQ_MAX) return XPROD_ROWB / (int)esize(h);
-    return XPROD_NT_ROWS;
+    return XPROD_ROWB / (int)esize(h);
 }
 
 static void pack_mask_cols(const int *mask, int k, int ncols, bool transposed_input, int ld_in, std::vector<unsigned long long> &out, int npadded,
@@ -627,7 +611,6 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
             }
         }
         HIPCHK(h, hipMalloc(&h->H64, (size_t)h->KP * h->mpad * 8));
-        HIPCHK(h, hipMalloc(&h->Hop, (size_t)h->mpad * h->KP * es + 4096));
         if (h->prec == NNLM_PREC_F32) HIPCHK(h, hipMalloc(&h->Hkq, (size_t)h->KP * h->mpad * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->Wmask, (size_t)h->npad * h->MW * 8));
         HIPCHK(h, hipMalloc(&h->Hmask, (size_t)h->mpad * h->MW * 8));
@@ -664,18 +647,10 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
             for (int q = 0; q < k; q++) h64[(size_t)q * mpad + j] = H[(size_t)j * k + q]; // H is k x m column-major
     HIPCHK(h, hipMemcpy(h->W64, w64.data(), w64.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->H64, h64.data(), h64.size() * 8, hipMemcpyHostToDevice));
-    if (h->prec == NNLM_PREC_F64) {
-        std::vector<double> hop((size_t)mpad * KP, 0.0);
-        for (int j = 0; j < m; j++)
-            for (int q = 0; q < k; q++) hop[(size_t)j * KP + q] = h64[(size_t)q * mpad + j];
-        HIPCHK(h, hipMemcpy(h->Hop, hop.data(), hop.size() * 8, hipMemcpyHostToDevice));
-    } else {
-        std::vector<float> wop((size_t)KP * npad), hop((size_t)mpad * KP, 0.f);
+    if (h->prec != NNLM_PREC_F64) {
+        std::vector<float> wop((size_t)KP * npad);
         for (size_t e = 0; e < wop.size(); e++) wop[e] = (float)w64[e];
-        for (int j = 0; j < m; j++)
-            for (int q = 0; q < k; q++) hop[(size_t)j * KP + q] = (float)h64[(size_t)q * mpad + j];
         HIPCHK(h, hipMemcpy(h->Wop, wop.data(), wop.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->Hop, hop.data(), hop.size() * 4, hipMemcpyHostToDevice));
     }
     std::vector<unsigned long long> mk;
     h->has_wmask = Wm != nullptr;
@@ -718,34 +693,26 @@ template <typename T, int NKQ, int KT>
 static void launch_xprod(nnlm_handle *h, int which, const HalfPlan &p)
 {
     const int KP = 16 * (NKQ + (KT > 0 ? 1 : 0)); // = h->KP
-    if (which == 1) {
-        dim3 grid(p.tiles_x, p.S);
-        const int lds = xprod_tn_lds_bytes(KP);
-        hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    dim3 grid(p.tiles_x, p.S);
+    const int lds = xprod_tn_lds_bytes(KP);
+    hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (which == 1)
         xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A + (size_t)p.col_off * h->npad, h->npad, (const T *)h->Wop,
                                                                               h->npad, h->Cx + p.col_off, h->mpad, (size_t)KP * h->mpad, p.stage_begin,
                                                                               p.stage_end, p.sps);
-    } else {
-        dim3 grid(p.tiles_x, p.S);
-        const int lds = xprod_nt_lds_bytes<T>(KP);
-        hipFuncSetAttribute((const void *)xprod_nt_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        xprod_nt_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A + p.col_off, h->npad, (const T *)h->Hop, h->Cx + p.col_off,
-                                                                              h->npad, (size_t)KP * h->npad, p.stage_begin, p.stage_end, p.sps);
-    }
+    else // roles swapped on the transposed copy (ensure_AT ran): rows of A are the columns solved, H (master, [KP][mpad]) the fixed factor
+        xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->AT + (size_t)p.col_off * h->mpad, h->mpad, (const T *)h->H64,
+                                                                              h->mpad, h->Cx + p.col_off, h->npad, (size_t)KP * h->npad, p.stage_begin,
+                                                                              p.stage_end, p.sps);
 }
 
 // MFMA tiles / VALU tail rows for rank k: k = 16*NKQ + rem; a remainder of 1..4 rows (with at least one full tile) is
-// not padded to a whole 16-wide MFMA tile but handled as 2 or 4 tail rows (k_xprod.h).  NNLM_XPROD_TAIL=0 disables it.
+// not padded to a whole 16-wide MFMA tile but handled as 2 or 4 tail rows (k_xprod.h).
 template <typename T>
 static void launch_xprod_nkq(nnlm_handle *h, int which, const HalfPlan &p)
 {
-    static int tail_ok = -1;
-    if (tail_ok < 0) {
-        const char *e = getenv("NNLM_XPROD_TAIL");
-        tail_ok = (e && atoi(e) == 0) ? 0 : 1;
-    }
     const int full = h->k / 16, rem = h->k % 16;
-    if (tail_ok && full >= 1 && rem >= 1 && rem <= 4) {
+    if (full >= 1 && rem >= 1 && rem <= 4) {
         const int kt = rem <= 2 ? 2 : 4;
         switch (full * 10 + kt) {
         case 12: launch_xprod<T, 1, 2>(h, which, p); return;
@@ -932,19 +899,19 @@ static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, in
     if (nb < 1) nb = 1;
     if (generic_rank(h)) {
         dim3 grid(nb, h->NKQ * (h->NKQ + 1) / 2);
-        gram_partial_generic_kernel<<<grid, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->NKQ, h->gslabs);
-        gram_reduce_kernel<<<(h->KP * h->KP + 255) / 256, 256, 0, h->stream_g>>>(h->gslabs, nb, h->KP, h->Graw);
+        gram_partial_generic_kernel<<<grid, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->NKQ, h->gslabs);
+        gram_reduce_kernel<<<(h->KP * h->KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw);
         *nslabs = nb;
         return;
     }
     switch (h->NKQ) {
-    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream_g>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
     }
     const int KP = h->KP;
-    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream_g>>>(h->gslabs, nb, KP, h->Graw);
+    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
     *nslabs = nb;
 }
 
@@ -1081,32 +1048,42 @@ static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
     return NNLM_OK;
 }
 
-template <typename T, int EPT>
-static void launch_kl_m(int method, const KlArgs &a, hipStream_t s)
+// strict fp64 mode: kl_reg64_kernel (k_kl.h).  EPT2 = double2 chunks of the contraction per thread (rounded up to an
+// instantiated value), C = columns per workgroup (C * EPT2 <= 20 chunks = 160 state registers)
+template <int EPT2, int C>
+static void launch_kl64_m(int method, const Kl64Args &ka, hipStream_t s)
 {
-    if (a.ncols <= a.col0) return;
-    if (method == 3) kl_update_kernel<T, EPT, 3><<<a.ncols - a.col0, KL_THREADS, 0, s>>>(a);
-    else kl_update_kernel<T, EPT, 4><<<a.ncols - a.col0, KL_THREADS, 0, s>>>(a);
+    const int nb = (ka.ncols - ka.colbase + C - 1) / C;
+    if (nb <= 0) return;
+    const size_t lds = kl64_lds_bytes(EPT2, C, ka.k);
+    if (method == 3) {
+        hipFuncSetAttribute((const void *)kl_reg64_kernel<EPT2, C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_reg64_kernel<EPT2, C, 3><<<nb, KL64_THREADS, lds, s>>>(ka);
+    } else {
+        hipFuncSetAttribute((const void *)kl_reg64_kernel<EPT2, C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_reg64_kernel<EPT2, C, 4><<<nb, KL64_THREADS, lds, s>>>(ka);
+    }
 }
-
-template <typename T>
-static void launch_kl(int method, const KlArgs &a, hipStream_t s)
+static int kl64_ept2(int p) { return ((p + 1) / 2 + KL64_THREADS - 1) / KL64_THREADS; } // > 20: too long for the register-resident kernel
+static bool kl64_fits(int p, int k) { return kl64_ept2(p) <= 20 && kl64_lds_bytes(kl64_ept2(p) <= 5 ? 5 : (kl64_ept2(p) <= 10 ? 10 : 20), 4, k) <= (size_t)160 * 1024; }
+static void launch_kl64(int method, const Kl64Args &ka, hipStream_t s)
 {
-    const int ept = (a.p + KL_THREADS - 1) / KL_THREADS;
-    if (ept <= 1) launch_kl_m<T, 1>(method, a, s);
-    else if (ept <= 2) launch_kl_m<T, 2>(method, a, s);
-    else if (ept <= 4) launch_kl_m<T, 4>(method, a, s);
-    else if (ept <= 8) launch_kl_m<T, 8>(method, a, s);
-    else if (ept <= 16) launch_kl_m<T, 16>(method, a, s);
-    else if (ept <= 24) launch_kl_m<T, 24>(method, a, s);
-    else if (ept <= 32) launch_kl_m<T, 32>(method, a, s);
-    else if (ept <= 40) launch_kl_m<T, 40>(method, a, s);
-    else if (ept <= 48) launch_kl_m<T, 48>(method, a, s);
-    else launch_kl_m<T, 64>(method, a, s);
+    const int e = kl64_ept2(ka.p);
+    if (e <= 1) launch_kl64_m<1, 4>(method, ka, s);
+    else if (e <= 2) launch_kl64_m<2, 4>(method, ka, s);
+    else if (e <= 3) launch_kl64_m<3, 4>(method, ka, s);
+    else if (e <= 5) launch_kl64_m<5, 4>(method, ka, s);
+    else if (e <= 7) launch_kl64_m<7, 2>(method, ka, s);
+    else if (e <= 10) launch_kl64_m<10, 2>(method, ka, s);
+    else if (e <= 12) launch_kl64_m<12, 1>(method, ka, s);
+    else if (e <= 14) launch_kl64_m<14, 1>(method, ka, s);
+    else if (e <= 16) launch_kl64_m<16, 1>(method, ka, s);
+    else if (e <= 18) launch_kl64_m<18, 1>(method, ka, s);
+    else launch_kl64_m<20, 1>(method, ka, s);
 }
 
 // F32 mode: kl_tile_kernel (k_kl.h).  EPT4 = float4 chunks of the contraction per thread, C = columns per workgroup
-// (C * EPT4 * 8 state registers per thread); NNLM_KL_TILE=0 forces kl_stream_kernel for A/B runs.
+// (C * EPT4 * 8 state registers per thread).
 template <int EPT4, int C>
 static void launch_kl_tile_m(int method, const KlTileArgs &ta, int nb, size_t lds, hipStream_t s)
 {
@@ -1126,9 +1103,8 @@ static int kl_tile_ept4(int p)
 }
 static bool kl_tile_fits(int p, int k, int mw_masked)
 {
-    static int on = getenv("NNLM_KL_TILE") ? atoi(getenv("NNLM_KL_TILE")) : 1;
     const int e = kl_tile_ept4(p);
-    return on && e > 0 && kl_tile_lds_bytes(p, k, kl_tile_cols(e), mw_masked) <= (size_t)160 * 1024 && 2 * round_up_i(k, 2) * ERRF_TILE * 4 <= 160 * 1024;
+    return e > 0 && kl_tile_lds_bytes(p, k, kl_tile_cols(e), mw_masked) <= (size_t)160 * 1024 && 2 * round_up_i(k, 2) * ERRF_TILE * 4 <= 160 * 1024;
 }
 static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
 {
@@ -1165,15 +1141,14 @@ static void launch_kl_stream(int method, const KlArgs &a, int mw, void *st, size
 }
 
 template <int NKQ>
-static void launch_colsolve_m(int method, const SweepArgs &a, size_t g_stride, hipStream_t s)
+static void launch_colsolve_m(const SweepArgs &a, size_t g_stride, hipStream_t s) // Lee's multiplicative updates, per-column Grams
 {
     const int nb = (a.ncols - a.col0 + 3) / 4;
     if (nb <= 0) return;
-    if (method == 1) colsolve_ls_kernel<NKQ, 1><<<nb, 256, 0, s>>>(a, g_stride);
-    else colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
+    colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
 }
 
-// F32 mode, SCD: colsolve_fast_kernel (scaled rows of G, six instructions per coordinate); NNLM_COLSOLVE_FAST=0 for A/B runs
+// F32 mode, SCD: colsolve_fast_kernel (scaled rows of G, six instructions per coordinate)
 template <int NKQ>
 static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStream_t s)
 {
@@ -1190,8 +1165,7 @@ static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStrea
 }
 static bool colsolve_fast_ok(const nnlm_handle *h, int method)
 {
-    static int on = getenv("NNLM_COLSOLVE_FAST") ? atoi(getenv("NNLM_COLSOLVE_FAST")) : 1;
-    return on && method == 1 && h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX;
+    return method == 1 && h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX;
 }
 static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_stride)
 {
@@ -1201,14 +1175,6 @@ static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_st
     case 3: launch_colsolve_fast_m<3>(a, g_stride, h->stream); break;
     default: launch_colsolve_fast_m<4>(a, g_stride, h->stream); break;
     }
-}
-
-// Largest column shard the wave-per-column sweep takes over from the workgroup-specialised one (multi-GPU dense path);
-// NNLM_SWEEP_WAVE_COLS overrides it (0 = never)
-static int sweep_wave_cols_max()
-{
-    static int v = getenv("NNLM_SWEEP_WAVE_COLS") ? atoi(getenv("NNLM_SWEEP_WAVE_COLS")) : 4096;
-    return v;
 }
 
 template <int NKQ>
@@ -1231,10 +1197,8 @@ static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size
         launch_colsolve_fast(h, a, g_stride);
         return;
     }
-    // SCD in the reference's arithmetic (strict mode, NNLM_COLSOLVE_FAST=0): the unrolled lane-local form; NNLM_COLSOLVE_STRICT=0 keeps
-    // colsolve_ls_kernel (which also runs the Lee updates)
-    static int strict_env = getenv("NNLM_COLSOLVE_STRICT") ? atoi(getenv("NNLM_COLSOLVE_STRICT")) : 1;
-    if (strict_env && method == 1 && h->k <= NNLM_KQ_MAX) {
+    // SCD in the reference's arithmetic (strict mode): the unrolled lane-local form; Lee's updates: colsolve_lee_kernel
+    if (method == 1) {
         switch (h->NKQ) {
         case 1: launch_colsolve_strict_m<1>(a, g_stride, h->stream); break;
         case 2: launch_colsolve_strict_m<2>(a, g_stride, h->stream); break;
@@ -1244,10 +1208,10 @@ static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size
         return;
     }
     switch (h->NKQ) {
-    case 1: launch_colsolve_m<1>(method, a, g_stride, h->stream); break;
-    case 2: launch_colsolve_m<2>(method, a, g_stride, h->stream); break;
-    case 3: launch_colsolve_m<3>(method, a, g_stride, h->stream); break;
-    default: launch_colsolve_m<4>(method, a, g_stride, h->stream); break;
+    case 1: launch_colsolve_m<1>(a, g_stride, h->stream); break;
+    case 2: launch_colsolve_m<2>(a, g_stride, h->stream); break;
+    case 3: launch_colsolve_m<3>(a, g_stride, h->stream); break;
+    default: launch_colsolve_m<4>(a, g_stride, h->stream); break;
     }
 }
 
@@ -1292,23 +1256,18 @@ static size_t yrow_bytes(const nnlm_handle *h)
     return a > b ? a : b;
 }
 
-// NNLM_NA_GRAM=valu keeps the VALU kernel (A/B).  Per-column Grams of columns [c0, c1) (row lists exist for all ncols columns)
+// Per-column Grams of columns [c0, c1) (row lists exist for all ncols columns)
 static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols, int c0, int c1)
 {
-    static int use_mfma = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "valu") == 0) ? 0 : 1;
     const int nc = c1 - c0;
     if (nc <= 0) return NNLM_OK;
     const double *Ym = (which == 1) ? h->W64 : h->H64; // fixed factor [KP][ldy]; the kernels gather its ROWS: row-major copy Yrow [p][KP]
     const int ldy = (which == 1) ? h->npad : h->mpad;
-    static int g32 = (getenv("NNLM_NA_GRAM") && strcmp(getenv("NNLM_NA_GRAM"), "f64") == 0) ? 0 : 1;
-    const bool f32rows = use_mfma && !generic_rank(h) && h->prec == NNLM_PREC_F32 && g32;
-    // F32 mode with split-fp16 cross products: the Grams on the fp16 matrix cores from the split copy of the rows (na_gram_f16_kernel).
-    // max|fixed factor| is in *fixed_maxw (prepare_factor16 ran for this half-step's cross product).  NNLM_NA_GRAM_F16=0: fp32 rows.
-    static int f16_env = getenv("NNLM_NA_GRAM_F16") ? atoi(getenv("NNLM_NA_GRAM_F16")) : 1;
-    const bool f16rows = f32rows && h->x16 && f16_env;
-    if (f16rows) {
-        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
-        if (rc != NNLM_OK) return rc;
+    int rc = ensure_na_lists(h, which, bits, words, p, ncols);
+    if (rc != NNLM_OK) return rc;
+    // F32 mode: the Grams on the fp16 matrix cores from the split copy of the rows (na_gram_f16_kernel).
+    // max|fixed factor| is in *fixed_maxw (prepare_factor16 ran for this half-step's cross product).
+    if (h->x16 && !generic_rank(h)) {
         // [p + 64 rows][64 hi | 64 lo halves]; rows p .. are zero (the kernel's "no row" index)
         factor16c_kernel<<<p / 64 + 1, 256, 0, h->stream>>>(Ym, ldy, p, h->k, h->fixed_maxw ? h->fixed_maxw : h->maxbits, h->scal_exp + 3, (uint32_t *)h->Yrow);
         const int nb = (nc + 3) / 4;
@@ -1322,63 +1281,24 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
 #undef NNLM_NAGH
         return NNLM_OK;
     }
-    if (f32rows) factor_rows_kernel<float><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, (float *)h->Yrow);
-    else factor_rows_kernel<double><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, h->Yrow);
+    factor_rows_kernel<double><<<(p + 255) / 256, 256, 0, h->stream>>>(Ym, ldy, p, h->KP, h->Yrow);
     if (generic_rank(h)) { // rank > 64: k_generic.h
-        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
-        if (rc != NNLM_OK) return rc;
         const int lds = 16 * h->KP * 8;
         na_gram_generic_kernel<<<nc, 256, lds, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->Graw, h->Gcols, c0);
         return NNLM_OK;
     }
-    if (use_mfma) {
-        int rc = ensure_na_lists(h, which, bits, words, p, ncols);
-        if (rc != NNLM_OK) return rc;
-        const int nb = (nc + 3) / 4;
-        // F32 mode: fp32 copy of the factor rows + v_mfma_f32_16x16x4_f32 (NNLM_NA_GRAM=f64 keeps the fp64 matrix cores for A/B runs)
-        static int tail_env = getenv("NNLM_NA_GRAM_TAIL") ? atoi(getenv("NNLM_NA_GRAM_TAIL")) : 1;
-        static int lds_env = getenv("NNLM_NA_GRAM_LDS") ? atoi(getenv("NNLM_NA_GRAM_LDS")) : 1;
-        const int ntail = h->k - 16 * (h->NKQ - 1);
-        if (lds_env) { // rows gathered by LDS-DMA (k_missing.h, na_gram_lds_kernel); NNLM_NA_GRAM_LDS=0: register gathers
-            const bool tl = tail_env && h->NKQ >= 2 && (ntail == 1 || ntail == 2);
-#define NNLM_NAGL(T_, N_, TL_) na_gram_lds_kernel<T_, N_, TL_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const T_ *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
-#define NNLM_NAGL_T(T_)                                                           \
-    switch (h->NKQ) {                                                             \
-    case 1: NNLM_NAGL(T_, 1, false); break;                                       \
-    case 2: if (tl) NNLM_NAGL(T_, 1, true); else NNLM_NAGL(T_, 2, false); break;  \
-    case 3: if (tl) NNLM_NAGL(T_, 2, true); else NNLM_NAGL(T_, 3, false); break;  \
-    default: if (tl) NNLM_NAGL(T_, 3, true); else NNLM_NAGL(T_, 4, false); break; \
-    }
-            if (f32rows) { NNLM_NAGL_T(float) } else { NNLM_NAGL_T(double) }
-#undef NNLM_NAGL_T
-#undef NNLM_NAGL
-            return NNLM_OK;
-        }
-        if (f32rows) {
-#define NNLM_NAG(T_, N_) na_gram_mfma_kernel<T_, N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const T_ *)h->Yrow, h->Graw, h->Gcols, c1, c0)
-            switch (h->NKQ) {
-            case 1: NNLM_NAG(float, 1); break;
-            case 2: NNLM_NAG(float, 2); break;
-            case 3: NNLM_NAG(float, 3); break;
-            default: NNLM_NAG(float, 4); break;
-            }
-        } else {
-            switch (h->NKQ) {
-            case 1: NNLM_NAG(double, 1); break;
-            case 2: NNLM_NAG(double, 2); break;
-            case 3: NNLM_NAG(double, 3); break;
-            default: NNLM_NAG(double, 4); break;
-            }
-#undef NNLM_NAG
-        }
-        return NNLM_OK;
-    }
+    // strict mode: fp64 rows gathered by LDS-DMA, v_mfma_f64_16x16x4_f64 (k_missing.h, na_gram_lds_kernel); tail form for k = 16 j + 1, + 2
+    const int nb = (nc + 3) / 4;
+    const int ntail = h->k - 16 * (h->NKQ - 1);
+    const bool tl = h->NKQ >= 2 && (ntail == 1 || ntail == 2);
+#define NNLM_NAGL(N_, TL_) na_gram_lds_kernel<double, N_, TL_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const double *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
     switch (h->NKQ) {
-    case 1: na_gram_kernel<1><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
-    case 2: na_gram_kernel<2><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
-    case 3: na_gram_kernel<3><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
-    default: na_gram_kernel<4><<<nc, 256, 0, h->stream>>>(bits, words, p, h->Yrow, h->Graw, h->Gcols, c0); break;
+    case 1: NNLM_NAGL(1, false); break;
+    case 2: if (tl) NNLM_NAGL(1, true); else NNLM_NAGL(2, false); break;
+    case 3: if (tl) NNLM_NAGL(2, true); else NNLM_NAGL(3, false); break;
+    default: if (tl) NNLM_NAGL(3, true); else NNLM_NAGL(4, false); break;
     }
+#undef NNLM_NAGL
     return NNLM_OK;
 }
 
@@ -1444,7 +1364,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         a.bits = h->any_missing ? h->miss : nullptr; a.words = h->npad / 32;
         a.p = h->n; a.ncols = h->m;
         a.mask = h->has_hmask ? h->Hmask : nullptr;
-        a.op = h->Hop; a.op_mode = 2; a.op_ld = h->KP;
+        a.op = nullptr; a.op_mode = 0; a.op_ld = 0;
     } else {
         a.X = h->W64; a.Xout = h->W64b[h->wcur ^ 1]; a.ldx = h->npad; a.Y = h->H64; a.ldy = h->mpad;
         a.a_col_stride = 1; a.a_i_stride = (size_t)h->npad;
@@ -1532,8 +1452,61 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ta.op_ld = a.op_ld;
         ta.sweeps = a.sweeps;
         launch_kl_tile(method, ta, h->stream);
-    } else if (h->prec == NNLM_PREC_F64 && !generic_rank(h) && a.p <= KL_MAX_P) {
-        launch_kl<double>(method, a, h->stream); // strict mode, state in registers
+    } else if (h->prec == NNLM_PREC_F64 && !generic_rank(h) && kl64_fits(a.p, h->k)) {
+        // ---- strict fp64 mode: register-resident fp64 state, the row of the fixed factor parked in LDS between the passes ----
+        Kl64Args ka;
+        if (!h->What64) HIPCHK(h, hipMalloc(&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096));
+        if (!h->klsw) HIPCHK(h, hipMalloc(&h->klsw, (size_t)h->KP * 8));
+        const int k4 = round_up_i(h->k, 4);
+        if (which == 1) { // What64[j][i], the layout of A
+            dim3 grid(h->npad / 64, h->mpad / 64);
+            wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->W64, h->npad, h->H64, h->mpad, k4, h->What64, (size_t)h->npad, h->n, h->m);
+            ka.Adata = (const double *)h->A;
+        } else { // roles swapped: What64^T [row of A][column of A], next to the transposed copy of A
+            int rc = ensure_AT(h);
+            if (rc != NNLM_OK) return rc;
+            dim3 grid(h->mpad / 64, h->npad / 64);
+            wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->H64, h->mpad, h->W64, h->npad, k4, h->What64, (size_t)h->mpad, h->m, h->n);
+            ka.Adata = (const double *)h->AT;
+        }
+        ka.lda = (size_t)ld_con;
+        ka.Yinit = h->What64;
+        ka.Y = a.Y;
+        ka.ldy = a.ldy;
+        ka.p = a.p;
+        ka.ncols = a.ncols;
+        ka.k = h->k;
+        ka.X = a.X;
+        ka.Xout = a.Xout;
+        ka.ldx = a.ldx;
+        ka.colbase = a.col0;
+        ka.ldo = a.ldo;
+        ka.ocol0 = a.ocol0;
+        kl_sumw_kernel<<<h->k, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->klsw);
+        ka.sumw = h->klsw;
+        ka.sumw_cols = nullptr;
+        ka.ldsw = h->KP;
+        if (h->any_missing) { // row sums over each column's non-missing entries (src/update_with_missing.cpp:122,130)
+            if (!h->Yrow) HIPCHK(h, hipMalloc(&h->Yrow, yrow_bytes(h)));
+            if (!h->klsw_cols) HIPCHK(h, hipMalloc(&h->klsw_cols, (size_t)(h->n > h->m ? h->n : h->m) * h->KP * 8));
+            int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, ncols_all);
+            if (rc != NNLM_OK) return rc;
+            factor_rows_kernel<<<(a.p + 255) / 256, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->KP, h->Yrow);
+            kl_sumw_cols_kernel<<<(ncols_all + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
+                                                                           h->klsw, h->klsw_cols, h->KP, ncols_all);
+            ka.sumw_cols = h->klsw_cols;
+        }
+        ka.r0 = reg[0];
+        ka.r1 = reg[1];
+        ka.r2 = reg[2];
+        ka.mask = a.mask;
+        ka.max_iter = inner_max_iter;
+        ka.rel_tol = inner_rel_tol;
+        ka.op = a.op;
+        ka.op_mode = a.op_mode;
+        ka.op_ld = a.op_ld;
+        ka.sweeps = a.sweeps;
+        launch_kl64(method, ka, h->stream);
     } else {
         // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel) ----
         const size_t need = (size_t)ncols_all * 2 * ld_con * esize(h);
@@ -1597,7 +1570,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     HalfPlan p = plan_half(h, which, colshard ? 0 : h->rank, colshard ? 1 : h->nranks);
     if (colshard) { // own columns only, whole contraction
         const ShardCols sc = shard_cols(h, (which == 1) ? h->m : h->n);
-        const int tile = (which == 1 || h->x16 || generic_rank(h)) ? XPROD_TN_BJ : 64 * (16 / (int)esize(h)); // (rank > 64: the TN kernel on A^T)
+        const int tile = XPROD_TN_BJ;
         p.col_off = sc.col0;
         p.tiles_x = (sc.col1 - sc.col0 + tile - 1) / tile;
         if (p.tiles_x > 0) split_plan(p.tiles_x, p.stage_end - p.stage_begin, &p.S, &p.sps);
@@ -1650,7 +1623,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
                 h->pack_ready = true;
             }
             {
-                ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
+                ProfScope ps(h, which == 1 ? P_XPROD_H : (h->fuse_err ? P_XPROD_W_ERR : P_XPROD_W));
                 launch_xprod16(h, which, p);
             }
             if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream));
@@ -1676,38 +1649,19 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             h->consts_ready = true; // (the strict kernel's constants; the one-wavefront kernel packs its operand image at launch)
         }
         {
-            ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
+            ProfScope ps(h, which == 1 ? P_XPROD_H : (h->fuse_err ? P_XPROD_W_ERR : P_XPROD_W));
             launch_xprod16(h, which, p);
         }
         if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream));
         return half_step_solve(h, which, reg, inner_max_iter, inner_rel_tol, method, p.S, speculative, phase);
     }
-    // The fixed factor is final once everything already on the main stream has run: the Gram kernels (stream_g) start
-    // there and overlap the A-streaming cross product (the xprod launch leaves 19 of 256 CUs idle at config 2).
-    HIPCHK(h, hipEventRecord(h->ev_factor, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream_g, h->ev_factor, 0));
-    // 1. cross product slabs
-    if (h->x16) {
-        // (multi-GPU: the unpack of the previous half-step left max|fixed factor| behind -- no absmax pass)
-        const int solved_by = (which == 1) ? 0 : 1; // the half-step that solved this half-step's fixed factor
-        unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : nullptr;
-        prepare_factor16(h, which, mb);
-        h->fixed_maxw = mb ? mb : h->maxbits;
-    }
-    if (p.tiles_x > 0) {
-        ProfScope ps(h, which == 1 ? P_XPROD_H : P_XPROD_W);
-        if (generic_rank(h)) {
-            int rcx = launch_xprod_generic(h, which, p);
-            if (rcx != NNLM_OK) return rcx;
-        } else if (h->prec == NNLM_PREC_F64) launch_xprod_nkq<double>(h, which, p);
-        else if (h->x16) launch_xprod16(h, which, p);
-        else launch_xprod_nkq<float>(h, which, p);
-    }
-    if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream)); // the error block starts once A is no longer streamed
-    // 2. Gram of the fixed factor over this rank's contraction slab
+    // 1. Gram of the fixed factor over this rank's contraction slab -- on the main stream, AHEAD of the cross product.  (Rounds 1-2
+    // ran it on a second stream next to the A-streaming kernel: the cross product owns every CU's LDS, the Gram kernel got slots
+    // only as its workgroups retired and stretched from 0.03 to 0.5-1.0 ms while slowing the cross product down with it --
+    // profiles/r03_f64_cfg2_a_kernel_stats.csv: xprod_tn 0.44 .. 1.6 ms, gram_partial 0.03 .. 0.99 ms.)
     int gslabs = 0;
     {
-        ProfScope ps(h, P_GRAM, h->stream_g);
+        ProfScope ps(h, P_GRAM, h->stream);
         const int CE = stage_elems(h, which);
         int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
         const int lim = (which == 1) ? h->n : h->m;
@@ -1716,8 +1670,29 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs);
         else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs);
     }
-    HIPCHK(h, hipEventRecord(h->ev_gram, h->stream_g));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gram, 0));
+    // 2. cross product slabs
+    if (h->x16) {
+        // (multi-GPU: the unpack of the previous half-step left max|fixed factor| behind -- no absmax pass)
+        const int solved_by = (which == 1) ? 0 : 1; // the half-step that solved this half-step's fixed factor
+        unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : nullptr;
+        prepare_factor16(h, which, mb);
+        h->fixed_maxw = mb ? mb : h->maxbits;
+    }
+    if (p.tiles_x > 0) {
+        ProfScope ps(h, which == 1 ? P_XPROD_H : (h->fuse_err ? P_XPROD_W_ERR : P_XPROD_W));
+        if (generic_rank(h)) {
+            int rcx = launch_xprod_generic(h, which, p);
+            if (rcx != NNLM_OK) return rcx;
+        } else if (h->x16) launch_xprod16(h, which, p);
+        else {
+            if (which == 0) {
+                int rca = ensure_AT(h);
+                if (rca != NNLM_OK) return rca;
+            }
+            launch_xprod_nkq<double>(h, which, p);
+        }
+    }
+    if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream)); // the error block starts once A is no longer streamed
     // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer; ONE all-reduce sums it over ranks
     if (h->sharded && !colshard) {
         const int ld = (which == 1) ? h->mpad : h->npad;
@@ -1743,7 +1718,7 @@ static int shard_unpack(nnlm_handle *h, int which)
     h->upk_max_for = maxw ? which : -1;
     if (which == 1)
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols, h->H64,
-                                                                                   h->mpad, h->Hop, 2, h->KP, f64, maxw);
+                                                                                   h->mpad, nullptr, 0, 0, f64, maxw);
     else
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols,
                                                                                    h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
@@ -1820,9 +1795,9 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             a.slab_stride = (size_t)h->KP * h->mpad;
             a.ncols = h->m;
             a.mask = h->has_hmask ? h->Hmask : nullptr;
-            a.op = h->Hop;
-            a.op_mode = 2;
-            a.op_ld = h->KP;
+            a.op = nullptr; // (H has no GEMM-operand copy: every consumer reads the master or makes its own split / fp32 copy)
+            a.op_mode = 0;
+            a.op_ld = 0;
         } else {
             a.X = h->W64;
             a.Xout = h->W64b[h->wcur ^ 1];
@@ -1861,10 +1836,6 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                 if (rcs != NNLM_OK) return rcs;
             } else
                 launch_colsolve(h, method, a, (size_t)h->KP * h->KP);
-        } else if (h->sharded && colsolve_fast_ok(h, method) && a.ncols - a.col0 <= sweep_wave_cols_max()) {
-            // a column shard too small to fill the chip's workgroup slots: the workgroup-specialised sweep takes ~0.19 ms however few
-            // columns it gets (2500 steps x ~180 cycles); one wavefront per column takes 2500 steps x ~40 cycles + 38 us per 1000 columns
-            launch_colsolve_fast(h, a, 0);
         } else if (a.ncols > a.col0) {
             int rcs = launch_sweep(h, method, a);
             if (rcs != NNLM_OK) return rcs;
@@ -2382,12 +2353,11 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below).  The error block
                 // (one more pass over A) starts together with it: since the cross product became HBM bound (k_xprod16.h) the
                 // two streams of A share the bandwidth, but the error block is then finished before the latency-bound sweep
-                // needs the CUs -- measured +2 % over holding it back until the cross product is done (NNLM_ERR_EARLY=0)
+                // needs the CUs -- measured +2 % over holding it back until the cross product is done
                 // Split-fp16 mode without missing values: that half-step's cross product streams A with H_i as its fixed
                 // factor while W_i is still current, so it evaluates the error sums of (W_i, H_i) on the way
-                // (xprod16_err_kernel) and no separate pass over A is needed (NNLM_ERR_FUSED=0: separate kernel).
-                static int fused_ok = getenv("NNLM_ERR_FUSED") ? atoi(getenv("NNLM_ERR_FUSED")) : 1;
-                h->fuse_err = fused_ok && h->x16 && !h->any_missing && !generic_rank(h);
+                // (xprod16_err_kernel) and no separate pass over A is needed.
+                h->fuse_err = h->x16 && !h->any_missing && !generic_rank(h);
                 h->fused_nb = 0;
                 rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true);
                 h->fuse_err = false;
@@ -2395,8 +2365,6 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                     g_last_error = h->err;
                     return rc;
                 }
-                static int err_early = getenv("NNLM_ERR_EARLY") ? atoi(getenv("NNLM_ERR_EARLY")) : 1;
-                if (!err_early) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
                 spec.pending = true;
             } else
                 h->fused_nb = 0;

@@ -137,6 +137,40 @@ __global__ __launch_bounds__(256, 2) void k_time(double *out, long long *cyc, in
         }
         a = m;
     }
+    else if (mode == 13) { // strict KL element body x 4: d = y + eps, quotient (rcp, 2 Newton, residual), fma into the sum, refresh
+        double num[4] = {v[0], v[1], v[2], v[3]}, yv[4] = {v[4] + 1, v[5] + 1, v[6] + 1, v[7] + 1}, acc4[2] = {0, 0};
+        for (int it = 0; it < n; it++) {
+            double den[4], r[4], t[4], q[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) den[i] = yv[i] + 1e-16;
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = __builtin_amdgcn_rcp(den[i]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], r[i], 1.0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = __builtin_fma(t[i], r[i], r[i]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[i] = num[i] * r[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = __builtin_fma(-den[i], q[i], num[i]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[i] = __builtin_fma(t[i], r[i], q[i]);
+            acc4[0] = __builtin_fma(b, q[0], acc4[0]); acc4[1] = __builtin_fma(b, q[1], acc4[1]);
+            acc4[0] = __builtin_fma(b, q[2], acc4[0]); acc4[1] = __builtin_fma(b, q[3], acc4[1]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) yv[i] = __builtin_fma(b, num[i], yv[i]);
+        }
+        a = acc4[0] + acc4[1] + yv[0] + yv[1] + yv[2] + yv[3];
+    } else if (mode == 14) { // 16 independent v_rcp_f64
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = __builtin_amdgcn_rcp(v[i]);
+        }
+    }
     long long s1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     double s = a;
 #pragma unroll
@@ -183,10 +217,10 @@ int main()
     hipMemset(d, 0, 4096 * 64 * 8);
     hipMalloc(&c, 16);
     const char *names[] = {"13 indep MFMA 4x4x4", "13 dependent MFMA 4x4x4", "13 MFMA + dependent v_max", "16 indep dpp mov", "8 x (max->2 dpp->fma) dependent",
-                           "16 indep fp64 FMA", "13 MFMA + 20 FMA (free order)", "13 MFMA then 20 FMA", "4 indep MFMA 16x16x4", "13 indep MFMA, distinct A", "13 indep MFMA, distinct A and B", "13 MFMA out of place", "step: 4 x (max, L, chain, L, L)"};
-    const int per[] = {13, 13, 14, 16, 8, 16, 33, 33, 4, 13, 13, 13, 20};
+                           "16 indep fp64 FMA", "13 MFMA + 20 FMA (free order)", "13 MFMA then 20 FMA", "4 indep MFMA 16x16x4", "13 indep MFMA, distinct A", "13 indep MFMA, distinct A and B", "13 MFMA out of place", "step: 4 x (max, L, chain, L, L)", "strict KL body x 4 elements", "16 indep v_rcp_f64"};
+    const int per[] = {13, 13, 14, 16, 8, 16, 33, 33, 4, 13, 13, 13, 20, 4, 16};
     for (int wpb : {1, 2}) // waves per SIMD on the measured CU: blocks of 256 x wpb threads
-        for (int mode = 0; mode < 13; mode++) {
+        for (int mode = 0; mode < 15; mode++) {
             const int n = 20000;
             for (int rep = 0; rep < 2; rep++) {
                 k_time<<<1, 64 * (wpb == 1 ? 1 : 5)>>>(d, c, n, mode); // 5 waves: wave 0 and wave 4 share SIMD 0
@@ -197,7 +231,7 @@ int main()
         }
     // chip-wide: the step pattern (mode 12) and plain MFMAs (mode 0) on every SIMD, 1 / 2 / 3 wavefronts per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {0, 12, 9})
+    for (int mode : {13, 14})
         for (int grid : {1, 64, 256, 512, 768}) {
             const int n = 20000; float ms = 0;
             for (int rep = 0; rep < 2; rep++) {

@@ -20,7 +20,7 @@ with nnlm_amd.Handle(0, prec) as h:
     t0 = time.perf_counter(); h.iterate(iters, z, z, inner, 1e-9, 1); h.sync(); dt = time.perf_counter() - t0
     mse = h.errors()[0]
     sw = h.take_sweeps() / (n + m) / iters
-    line = f"L={os.environ.get('NNLM_SWEEP_L','auto')} inner={inner} {iters} it {1e3*dt/iters:.3f} ms/it sweeps/col {sw:.2f} mse {mse:.9f} |"
+    line = f"inner={inner} {iters} it {1e3*dt/iters:.3f} ms/it sweeps/col {sw:.2f} mse {mse:.9f} |"
     for nm in ("xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors"):
         ms, cnt = h.profile_get(nm); line += f" {nm} {ms/max(cnt,1):.3f}"
     print(line, flush=True)

@@ -210,3 +210,46 @@ def test_f32_mode_stops_at_the_iteration_the_oracle_stops(seed, shape):
     if r["n_iteration"] == o["n_iteration"]:
         assert relF(W @ H, o["W"] @ o["H"]) < 1e-4
         assert np.allclose(r["target_error"], o["target_error"], rtol=1e-4)  # (targets ~1e-4 here: fp32 A leaves ~1e-9 absolute)
+
+
+def test_config3_strict_f64_full_size_one_iteration():
+    """BASELINE configs[2] through what the .Call boundary defaults to (strict fp64: kl_reg64_kernel + wh_store64_kernel):
+    one outer iteration of Lee's KL updates at full size against the oracle; one sweep per column, counted exactly."""
+    A, W0, H0 = inputs()
+    z = [0.0, 0.0, 0.0]
+    with nnlm_amd.Handle(0, _lib.PREC_F64) as h:
+        h.set_matrix(A)
+        h.set_factors(K, W0, H0)
+        r = h.run(z, z, 1, -1.0, 0, False, 1, 1e-9, 4, 1)
+        W1, H1 = h.get_factors()
+    o = ref.c_nnmf(A, K, W0, H0, None, None, z, z, 1, -1.0, 0, 0, False, 1, 1e-9, 4, 1)
+    ew, eh = relF(W1, o["W"]), relF(H1, o["H"])
+    d_mse = float(np.max(np.abs(r["mse_error"] - o["mse_error"]) / o["mse_error"]))
+    d_mkl = float(np.max(np.abs(r["mkl_error"] - o["mkl_error"]) / np.abs(o["mkl_error"])))
+    report("config3_strict_f64_1_iteration", relF_W=ew, relF_H=eh, max_rel_mse_trace=d_mse, max_rel_mkl_trace=d_mkl)
+    assert ew < 1e-9 and eh < 1e-9, (ew, eh)
+    assert np.array_equal(r["average_epoch"], o["average_epoch"])  # (N + M sweeps) / (N + M) = 1, exactly
+    assert d_mse < 1e-9 and d_mkl < 1e-9
+
+
+def test_config5_strict_f64_full_size_one_iteration():
+    """BASELINE configs[4] in the strict fp64 mode (na_gram_lds_kernel<double> + colsolve_strict_kernel + errors_kernel<double>
+    with missing bits): one outer iteration at full size, per-column sweep counts exact."""
+    A, W0, H0 = inputs()
+    A = A.copy()
+    A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+    reg = [0.01, 0.0, 0.01]
+    with nnlm_amd.Handle(0, _lib.PREC_F64) as h:
+        h.set_matrix(A)
+        h.set_factors(K, W0, H0)
+        r = h.run(reg, reg, 1, -1.0, 0, False, 50, 1e-9, 1, 1)
+        W1, H1 = h.get_factors()
+    o = ref.c_nnmf(A, K, W0, H0, None, None, reg, reg, 1, -1.0, 0, 0, False, 50, 1e-9, 1, 1)
+    ew, eh = relF(W1, o["W"]), relF(H1, o["H"])
+    d_mse = float(np.max(np.abs(r["mse_error"] - o["mse_error"]) / o["mse_error"]))
+    d_tgt = float(np.max(np.abs(r["target_error"] - o["target_error"]) / np.abs(o["target_error"])))
+    report("config5_strict_f64_1_iteration", relF_W=ew, relF_H=eh, max_rel_mse_trace=d_mse, max_rel_target_trace=d_tgt,
+           epoch_gpu=float(r["average_epoch"][-1]), epoch_oracle=float(o["average_epoch"][-1]))
+    assert ew < 1e-9 and eh < 1e-9, (ew, eh)
+    assert np.array_equal(r["average_epoch"], o["average_epoch"])
+    assert d_mse < 1e-9 and d_tgt < 1e-9
