@@ -63,24 +63,3 @@ __device__ static inline long long wave_sum_ll(long long v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
-#define SWEEP_WG_CONSTS 32 // doubles per block in the constants image of the strict SCD sweep (k_sweep_wg.h)
-
-// One entry of the constants image the chain wave of sweep_scd_wg_kernel reads (layout: k_sweep_wg.h); shared by
-// sweep_consts_kernel and gram_reduce_consts_kernel.
-template <class F> __device__ static inline double sweep_wg_const(F edited, int k, int nbk, int b, int i)
-{
-    const int nb = (b + 1 < nbk) ? b + 1 : 0;
-    if (i < 4) return 1.0 / edited(4 * b + i, 4 * b + i);
-    if (i < 8) return edited(4 * b + i - 4, 4 * b + i - 4);
-    if (i < 14) {
-        const int s2[6] = {1, 2, 2, 3, 3, 3}, s[6] = {0, 0, 1, 0, 1, 2};
-        return edited(4 * b + s2[i - 8], 4 * b + s[i - 8]);
-    }
-    if (i >= 16 && i < 32) {
-        const int ss = (i - 16) / 4, g = (i - 16) % 4, r = 4 * nb + ss;
-        if (!(r < k && 4 * b + g < k)) return 0.0;
-        return edited(r, 4 * b + g);
-    }
-    return 0.0;
-}

@@ -183,48 +183,3 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
         else ((float *)op)[(size_t)q * op_ld + col] = (float)v;
     }
 }
-
-// gram_reduce + the chain-wave constants of the SCD sweep (k_sweep_wg.h, layout of sweep_consts_kernel) in one launch:
-// 64 outputs per block, four threads per output (slabs g, g+4, ...; folded in a fixed order); the block that finishes last
-// (device counter, reset for the next launch) has all of G in front of it and writes the constants image.
-__global__ __launch_bounds__(256) void gram_reduce_consts_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
-                                                                 int k, double r0, double r1, double *__restrict__ consts,
-                                                                 unsigned *__restrict__ counter, unsigned *__restrict__ zero_word)
-{
-    __shared__ double part[4][64];
-    __shared__ int last_s;
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + e;
-    int a = idx / KP, b = idx % KP;
-    if ((a >> 4) > (b >> 4)) {
-        const int t = a;
-        a = b;
-        b = t;
-    }
-    const size_t src = (size_t)a * KP + b;
-    double s = 0.0;
-    for (int i = g; i < nslabs; i += 4) s += slabs[(size_t)i * KP * KP + src];
-    part[g][e] = s;
-    __syncthreads();
-    if (g == 0) G[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last_s = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!last_s) return;
-    __threadfence();
-    if (threadIdx.x == 0) {
-        *counter = 0u;
-        if (zero_word) *zero_word = 0u; // the max word the NEXT half-step's gram_partial accumulates into
-    }
-    const int nbk = (k + 3) / 4;
-    auto edited = [&](int c, int kc) -> double {
-        if (c >= k || kc >= k) return (c == kc) ? 1.0 : 0.0;
-        double v = __builtin_nontemporal_load(G + (size_t)c * KP + kc);
-        if (c == kc && r0 != r1) v += r0 - r1;
-        if (r1 != 0) v += r1;
-        if (c == kc) v += NNLM_TINY;
-        return v;
-    };
-    for (int t = threadIdx.x; t < nbk * SWEEP_WG_CONSTS; t += 256) consts[t] = sweep_wg_const(edited, k, nbk, t / SWEEP_WG_CONSTS, t % SWEEP_WG_CONSTS);
-}

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 //
 // colsolve_ls_kernel above spends ~15 fp64 instructions per coordinate (four v_readlane pairs, reciprocal + Markstein
 // quotient, compare, select): 2.9 ms per half-step at config 5 against 0.19-0.24 ms for the dense sweep.  This kernel runs
-// the same recurrence in the arithmetic of k_sweep_wgf.h (rows of G divided by their diagonal, nu = mu / G[q][q],
+// the same recurrence in the arithmetic of the fp32-operand mode (k_sweep_q.h) (rows of G divided by their diagonal, nu = mu / G[q][q],
 // d = max(-x, -nu): ONE instruction) with one wavefront per column, lane = coordinate, and six instructions per step:
 //     v_max_f64   dd   = max(-x, -nu)              every lane on its own coordinate; lane q's value is the step's delta
 //     v_readlane  d    = dd[q]            (x2)      -> SGPR pair
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 //     v_writelane xd[q] = d               (x2)      deltas of the sweep, added to x once per sweep
 // A coordinate's x only matters at its own step, so x is brought up to date once per sweep (x += xd) and the rel-change
 // test of src/base_algorithms.cpp:29-32 runs once per sweep on all lanes: 2|xd| > tol (x_new + x_old + eps).
-// Results differ from colsolve_ls_kernel by rounding only (the deviations listed for k_sweep_wgf.h in DESIGN.md section 2).
+// Results differ from colsolve_ls_kernel by rounding only (the deviations listed for the fp32-operand mode in DESIGN.md section 2).
 // Also the dense sweep for SMALL column counts (multi-GPU column shards): its duration is 2500 steps x ~40 cycles however
 // few columns there are, a quarter of the workgroup-specialised kernel's.
 // KR: coordinates with a register of the Gram row (k <= KR <= 16 NKQ): k = 50 takes 52 instead of 64 -- 123 instead of 147 VGPRs, four

@@ -56,7 +56,7 @@ struct SweepArgs {
     int op_ld;
     int op_f64;         // element type of op: 0 float, 1 double
     unsigned long long *sweeps; // += sum of per-column sweep counts
-    // k_sweep_wgf.h only (NULL elsewhere): what the NEXT half-step needs from the factor solved here, produced from the
+    // k_sweep_q.h only (NULL elsewhere): what the NEXT half-step needs from the factor solved here, produced from the
     // final x image while it is still in LDS -- its Gram partial sums and max|x| (the scale of its split-fp16 copy)
     unsigned *maxbits = nullptr;      // atomicMax of the float bit pattern of max|x| over the solved columns
     double *gram_slabs = nullptr;     // [workgroups][KP*KP]  Gram of each workgroup's 48 columns (upper tiles)

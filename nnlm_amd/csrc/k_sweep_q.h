@@ -2,14 +2,14 @@
 // wavefronts at all: the whole recurrence of scd_ls_update (reference src/base_algorithms.cpp:3-37) on
 // v_mfma_f64_4x4x4_4b_f64.
 //
-// What the workgroup-specialised kernel (k_sweep_wgf.h) paid per block of 4 coordinates -- one s_barrier and two LDS round
-// trips per role, ~500 of its ~690 cycles -- came from the operand layouts: the chain wanted
+// What the workgroup-specialised kernels of rounds 1-2 (one chain wavefront + three update wavefronts on v_mfma_f64_16x16x4) paid per
+// block of 4 coordinates -- one s_barrier and two LDS round trips per role, ~500 of ~690 cycles -- came from the operand layouts: the chain wanted
 // lane = column, the 16x16x4 matrix instruction wants lane = (coordinate, column).  The 4x4x4 instruction with 4 blocks
 // (probed on the box, scripts/exp/mfma44_exp.hip: A lane = 16 k + 4 blk + i, B lane = 16 k + 4 blk + j,
 // D lane = 16 i + 4 blk + j; 16.6 cycles back to back; cbsz / abid are ignored, scripts/exp/mfma44_cbsz.hip) has the SAME
 // lane map for its B operand and its result: lane (i, col) with col = 4 blk + j.  So with
 //      block beta = coordinates 4 beta .. 4 beta + 3,   accumulator acc[beta] at lane (i, col) = nu[4 beta + i][col]
-// (nu = mu / G[q][q], rows of G divided by their diagonal as in k_sweep_wgf.h) the deltas of a block, computed by the lanes
+// (nu = mu / G[q][q], rows of G divided by their diagonal) the deltas of a block, computed by the lanes
 // that hold its gradients, ARE the B operand of the rank-4 update of every other block -- nothing moves between lanes.
 //   * The four dependent coordinate steps of a block run on the matrix core as well: with L = the strictly lower part of the
 //     block's own 4x4 piece of G',   c <- max(-x, -(m0 + L c))   three times makes rows 0..s of c final after pass s
@@ -26,8 +26,12 @@
 //   * Columns that are done (rel_err <= rel_tol) are written to the x image in LDS at that moment and keep being computed
 //     (their lanes cost nothing); masked coordinates carry x = 0, nu = 1e300 in the loop (delta = -0) and take their value
 //     from the input when a column is written.
-// Same arithmetic as k_sweep_wgf.h up to the order in which a block's four deltas are added to a gradient (the matrix
-// core's); the epilogue (factor outputs, max|x|, Gram partial sums for the next half-step) is that kernel's.
+// STRICT = false (fp32-operand mode): rows of G divided by their diagonal, delta = max(-x, -nu) -- one instruction per chain pass.
+// STRICT = true (strict fp64 mode): the reference's arithmetic -- unscaled G, tmp = max(x - mu / G[q][q], 0) with the correctly
+// rounded quotient (reciprocal + one Markstein correction), delta = tmp - x, x = tmp; six instructions per chain pass, the
+// block's 1 / G[q][q] and G[q][q] arrive with its chain operand.  Both differ from the reference only in the order in which a
+// block's four deltas are added to a gradient (the matrix core's).  The epilogue leaves the factor outputs, max|x| and the Gram
+// partial sums for the next half-step behind.
 #pragma once
 #include "common.h"
 #include "k_sweep.h"
@@ -36,18 +40,19 @@
 #define SWEEPQ_THREADS 256
 #define SWEEPQ_COLS 64 // columns per workgroup, 16 per wavefront
 
-__host__ __device__ static inline int sweepq_np(int NB) { return (NB + 2) / 2; }                         // operand PAIRS per step
-__host__ __device__ static inline size_t sweepq_img_doubles(int NB) { return (size_t)NB * sweepq_np(NB) * 32 + 4 * NB; }
+__host__ __device__ static inline int sweepq_np(int NB, bool strict) { return (NB + (strict ? 4 : 2)) / 2; } // operand PAIRS per step
+__host__ __device__ static inline size_t sweepq_img_doubles(int NB, bool strict) { return (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB; }
 
 // Operand image, exactly as the kernel keeps it in LDS: img[((beta * NP + p) * 16 + li) * 2 + e], li = 4 kA + iA, entry s = 2 p + e:
 //   s < NB  : G'[4 s + iA][4 beta + kA]                       (operand of accumulator s for the deltas of block beta)
 //   s == NB : strictly lower part of G'[4 bn + iA][4 bn + kA], bn = (beta + 1) % NB   (chain operand of the NEXT block)
+//   strict only: s == NB + 1 : 1 / G[4 bn + kA][4 bn + kA],  s == NB + 2 : G[4 bn + kA][4 bn + kA]   (per-coordinate constants of the next block)
 // followed by rinv[q] = 1 / G[q][q], q < 4 NB.  G' = edited G (src/update_with_missing.cpp:20-24) with row r divided by its
-// diagonal (diagonal exactly 1); coordinates >= k are inert (identity).
+// diagonal (diagonal exactly 1) -- strict: the edited G itself; coordinates >= k are inert (identity).
 __global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1, int NB,
-                                                          double *__restrict__ img)
+                                                          double *__restrict__ img, int strict)
 {
-    const int NP = sweepq_np(NB);
+    const int NP = sweepq_np(NB, strict != 0);
     auto edited = [&](int c, int kc) -> double {
         if (c >= k || kc >= k) return (c == kc) ? 1.0 : 0.0;
         double g = Graw[(size_t)c * KPg + kc];
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restri
         if (c == kc) g += NNLM_TINY;
         return g;
     };
-    auto scaled = [&](int r, int c) -> double { return (r == c) ? 1.0 : edited(r, c) * (1.0 / edited(r, r)); };
+    auto scaled = [&](int r, int c) -> double { return strict ? edited(r, c) : ((r == c) ? 1.0 : edited(r, c) * (1.0 / edited(r, r))); };
     const int total = NB * NP * 32;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total + 4 * NB; e += gridDim.x * 256) {
         if (e >= total) {
@@ -66,9 +71,10 @@ __global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restri
         const int s = 2 * ((e >> 5) % NP) + (e & 1), beta = (e >> 5) / NP, li = (e >> 1) & 15, kA = li >> 2, iA = li & 3;
         double v = 0.0;
         if (s < NB) v = scaled(4 * s + iA, 4 * beta + kA);
-        else if (s == NB) {
+        else if (s <= NB + 2) {
             const int bn = (beta + 1) % NB;
-            v = (iA > kA) ? scaled(4 * bn + iA, 4 * bn + kA) : 0.0;
+            if (s == NB) v = (iA > kA) ? scaled(4 * bn + iA, 4 * bn + kA) : 0.0;
+            else if (strict) v = (s == NB + 1) ? 1.0 / edited(4 * bn + kA, 4 * bn + kA) : edited(4 * bn + kA, 4 * bn + kA);
         }
         img[e] = v;
     }
@@ -122,11 +128,12 @@ constexpr SqSched sq_sched(int NL)
 }
 
 // NT: the caller's rank padding KP = 16 NT (layout of the outputs and of the Gram slabs); NB = ceil(k / 4) blocks
-template <int NT, int NB, bool HAS_MASK>
-__global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
+template <int NT, int NB, bool HAS_MASK, bool STRICT>
+// (masked with k > 56: one wavefront per SIMD rather than spills)
+__global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && NB >= 15) ? 1 : 2)) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
 {
-    constexpr int KP = 16 * NT, NP = (NB + 2) / 2, XS = KP + 2;
-    static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 3, "NB = ceil(k / 4)");
+    constexpr int KP = 16 * NT, NP = (NB + (STRICT ? 4 : 2)) / 2, XS = KP + 2;
+    static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 1, "NB = ceil(k / 4)");
     __shared__ __attribute__((aligned(16))) double xl[SWEEPQ_COLS * XS]; // x[column][coordinate], final values
     __shared__ __attribute__((aligned(16))) double opl[NB * NP * 32];    // the operand image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int q = 4 * b + ri;
-        acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - acc[b] : -acc[b]) * rinv[q] : 0.0;
+        acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - acc[b] : -acc[b]) * (STRICT ? 1.0 : rinv[q]) : 0.0;
     }
     __syncthreads(); // operand image complete
     // this lane's operand values: lane (kA, blk, iA) reads entry li = 4 kA + iA of every operand (all four blk groups the same)
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
     if (HAS_MASK) {
 #pragma unroll
         for (int b = 0; b < NB; b++)
-            if ((mword >> (4 * b + ri)) & 1ull) x[b] = 0.0, acc[b] = 1e300; // delta = max(-0, -1e300) = -0 for good
+            if ((mword >> (4 * b + ri)) & 1ull) x[b] = 0.0, acc[b] = 1e150; // delta = max(-0, -1e150) = -0 (strict: max(0 - huge, 0) - 0) for good
     }
 #ifdef SWEEPQ_DEBUG
     if (a.op_mode == 99 && blockIdx.x == 0 && wave == 0) { // harness: the initial (scaled) gradients
@@ -221,6 +228,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
     // entering step 0: As[1] = operands of block NB - 1 (lazy products of d_pend = 0: any finite values), Lc = chain operand of block 0
     fetch(std::integral_constant<int, NB - 1>{}, As[1]);
     double Lc = As[1][NB];
+    double rinvc = STRICT ? As[1][NB + 1] : 0.0, gdc = STRICT ? As[1][NB + 2] : 0.0; // strict: 1 / G[q][q] and G[q][q] of the current block's coordinates
     sq_nop<8>(); // (the initial gradients come out of MFMAs; the first v_max below is inline asm)
 
     // One block.  The step is four stages  [v_max]  pre  [dependent MFMA]  post : three chain passes and the urgent product.
@@ -246,7 +254,13 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
 #define SQ_IC(v) std::integral_constant<int, (v)> {}
 #define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    c = sq_delta(xb, val_in);                                                                                           \
+    if constexpr (STRICT) {                                                                                             \
+        const double q0 = (val_in) * rinvc; /* mu / G[q][q], correctly rounded: reciprocal + one Markstein correction */ \
+        const double qq = __builtin_fma(__builtin_fma(-q0, gdc, (val_in)), rinvc, q0);                                  \
+        tmpx = __builtin_fmax(xb - qq, 0.0); /* src/base_algorithms.cpp:23-24 */                                         \
+        c = tmpx - xb;                                                                                                  \
+    } else                                                                                                              \
+        c = sq_delta(xb, val_in);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
     lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
     lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
     sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
     __builtin_amdgcn_sched_barrier(0);
-        double c, m;
+        double c, m, tmpx = 0.0;
         SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))
 #ifndef SWEEPQ_ABL_NOFETCH // (harness ablation: timing without the operand fetches)
         fetch(bc, Ac); // (the previous step's lazy products were the last readers of this set)
@@ -269,8 +283,11 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
 #undef SQ_IC
         const double d = c;
         // rel-change test (src/base_algorithms.cpp:29-32), division-free: 2|d| > tol (x + d + x + eps)
-        if (TEST) flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
-        x[B] = xb + d;
+        if (TEST) {
+            if constexpr (STRICT) flag |= 2.0 * fabs(d) > tol * (tmpx + xb + NNLM_TINY); // (0 > .. when tmp == Hj(k): the reference's `continue`)
+            else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
+        }
+        x[B] = STRICT ? tmpx : xb + d; // (strict: Hj(k) = tmp itself, src/base_algorithms.cpp:33)
 #ifdef SWEEPQ_DEBUG
         if (a.op_mode == 99 && t == 0 && blockIdx.x == 0 && wave == 0) {
             double *dbg = (double *)a.op + 1024 + B * 6 * 64;
@@ -279,6 +296,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 2) void sweep_scd_q_kernel(const Sw
 #endif
         d_pend = d;
         Lc = Ac[NB];
+        if constexpr (STRICT) rinvc = Ac[NB + 1], gdc = Ac[NB + 2];
         __builtin_amdgcn_sched_barrier(0);
     };
     // some live column of the wavefront has no coordinate yet that moved by more than rel_tol

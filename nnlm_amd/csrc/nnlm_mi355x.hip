@@ -18,7 +18,6 @@
 #include "k_missing.h"
 #include "k_prep.h"
 #include "k_sweep.h"
-#include "k_sweep_wg.h"
 #include "k_sweep_q.h"
 #include "k_xprod.h"
 #include "k_xprod16.h"
@@ -106,7 +105,6 @@ struct nnlm_handle {
     double *pack_send = nullptr; // [KP][cpr]: this rank's updated columns, contiguous for ncclAllGather
     double *pack_all = nullptr;  // [nranks][KP][cpr]
     size_t pack_elems = 0;
-    double *sweep_consts = nullptr;           // [16][SWEEP_WG_CONSTS] block constants of the chain wave (k_sweep_wg.h)
     double *sweepq_img = nullptr;             // operand image of sweep_scd_q_kernel (k_sweep_q.h), rewritten every half-step
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
@@ -121,7 +119,6 @@ struct nnlm_handle {
     bool sg_request = false;     // set by half_step for the sweep it is about to launch
     double *sg_slabs = nullptr;
     int mb_par = 0;
-    bool consts_ready = false;   // sweep_consts image already produced for this half-step (gram_reduce_consts_kernel)
     bool pack_ready = false;     // sweepq_img already produced for this half-step (the one-stream dense flow packs it ahead of the cross product)
     int *scal_exp = nullptr;     // device: {eA, eY, eW of the fused error block}
     float *What = nullptr;       // [mpad][npad] fp32 W^T H: starting state vectors of a KL half-step (wh_store_kernel), on first use
@@ -282,8 +279,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     if (hipMalloc(&h->scal, 16 * sizeof(double)) != hipSuccess || hipMalloc(&h->sweeps, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&h->sweep_consts, 16 * SWEEP_WG_CONSTS * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->sweepq_img, sweepq_img_doubles(16) * sizeof(double)) != hipSuccess ||
+        hipMalloc(&h->sweepq_img, sweepq_img_doubles(16, true) * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->maxbits, 8 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
@@ -386,7 +382,6 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     hipFree(h->sweeps);
     hipHostFree(h->host_res);
     hipFree(h->sweeps_tmp);
-    hipFree(h->sweep_consts);
     hipFree(h->sweepq_img);
     hipFree(h->maxbits);
     hipFree(h->scal_exp);
@@ -951,24 +946,31 @@ static int sweep_lanes_per_column(int ncols)
     return 1;
 }
 
-// SCD-LS of the fp32-operand mode: sweep_scd_q_kernel (k_sweep_q.h: one wavefront per 16 columns, the whole recurrence on the
-// 4x4x4 fp64 matrix instruction, rows of G divided by their diagonal).  The strict fp64 mode keeps the reference's arithmetic
-// (correctly rounded mu / G[q][q]) in the workgroup-specialised kernel (k_sweep_wg.h), which also takes ranks below 9 (the
-// one-wavefront kernel needs three blocks of 4 coordinates).
-static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k > 8 && h->k <= NNLM_KQ_MAX; }
+// SCD-LS for ranks up to 64, both modes: sweep_scd_q_kernel (k_sweep_q.h: one wavefront per 16 columns, the whole recurrence on the
+// 4x4x4 fp64 matrix instruction).  fp32-operand mode: rows of G divided by their diagonal, one instruction per chain pass; strict
+// fp64 mode: the reference's arithmetic (correctly rounded mu / G[q][q]).
+static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX; }
 
 template <int NT, int NB> static void launch_sweep_q_m(nnlm_handle *h, const SweepArgs &a, int nb)
 {
-    if (a.mask) sweep_scd_q_kernel<NT, NB, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
-    else sweep_scd_q_kernel<NT, NB, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+    if (h->prec == NNLM_PREC_F64) {
+        if (a.mask) sweep_scd_q_kernel<NT, NB, true, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+        else sweep_scd_q_kernel<NT, NB, false, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+    } else {
+        if (a.mask) sweep_scd_q_kernel<NT, NB, true, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+        else sweep_scd_q_kernel<NT, NB, false, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+    }
 }
 static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
 {
     const int nb = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS, NB = (a.k + 3) / 4;
     if (nb <= 0) return;
-    if (!h->pack_ready) sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img);
+    if (!h->pack_ready)
+        sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img, h->prec == NNLM_PREC_F64 ? 1 : 0);
     h->pack_ready = false;
     switch (NB) {
+    case 1: launch_sweep_q_m<1, 1>(h, a, nb); break;
+    case 2: launch_sweep_q_m<1, 2>(h, a, nb); break;
     case 3: launch_sweep_q_m<1, 3>(h, a, nb); break;
     case 4: launch_sweep_q_m<1, 4>(h, a, nb); break;
     case 5: launch_sweep_q_m<2, 5>(h, a, nb); break;
@@ -984,14 +986,6 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     case 15: launch_sweep_q_m<4, 15>(h, a, nb); break;
     default: launch_sweep_q_m<4, 16>(h, a, nb); break;
     }
-}
-
-template <int NT, bool HAS_MASK>
-static void launch_sweep_wg(nnlm_handle *h, const SweepArgs &a, int nb)
-{
-    const int lds = sweep_wg_lds_bytes(NT);
-    hipFuncSetAttribute((const void *)sweep_scd_wg_kernel<NT, HAS_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    sweep_scd_wg_kernel<NT, HAS_MASK><<<nb, SWEEP_WG_THREADS, lds, h->stream>>>(a, h->sweep_consts);
 }
 
 // rank > 64: one wavefront per column, coordinates in LDS (k_generic.h); g_stride != 0: per-column Grams (missing values)
@@ -1016,27 +1010,8 @@ static int launch_sweep_generic(nnlm_handle *h, int method, const SweepArgs &a, 
 static int launch_sweep(nnlm_handle *h, int method, const SweepArgs &a)
 {
     if (generic_rank(h)) return launch_sweep_generic(h, method, a, 0);
-    if (method == 1 && sweep_fast(h)) {
-        launch_sweep_q(h, a);
-        return NNLM_OK;
-    }
     if (method == 1) {
-        const int nb = (a.ncols - a.col0 + SWEEP_WG_COLS - 1) / SWEEP_WG_COLS;
-        if (nb <= 0) return NNLM_OK;
-        if (!h->consts_ready) sweep_consts_kernel<<<1, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, h->sweep_consts);
-        h->consts_ready = false;
-#define NNLM_WG_SWEEP(NT_)                                                                                              \
-    {                                                                                                                   \
-        if (a.mask) launch_sweep_wg<NT_, true>(h, a, nb);                                                               \
-        else launch_sweep_wg<NT_, false>(h, a, nb);                                                                     \
-    }
-        switch (h->NKQ) {
-        case 1: NNLM_WG_SWEEP(1) break;
-        case 2: NNLM_WG_SWEEP(2) break;
-        case 3: NNLM_WG_SWEEP(3) break;
-        default: NNLM_WG_SWEEP(4) break;
-        }
-#undef NNLM_WG_SWEEP
+        launch_sweep_q(h, a);
         return NNLM_OK;
     }
     // Lee's multiplicative updates: sweep_ls_kernel, L lanes per column
@@ -1127,17 +1102,20 @@ static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
 }
 
 template <typename T>
-static void launch_kl_stream(int method, const KlArgs &a, int mw, void *st, size_t ldst, hipStream_t s)
+static int launch_kl_stream(nnlm_handle *h, int method, const KlArgs &a, int mw, void *st, size_t ldst, hipStream_t s)
 {
     const size_t lds = (size_t)(a.k + 24) * 8;
-    if (a.ncols <= a.col0) return;
+    if (a.ncols <= a.col0) return NNLM_OK;
+    if (lds > (size_t)160 * 1024)
+        return fail(h, NNLM_ERR_UNSUPPORTED, "KL solver: rank %d needs %zu bytes of LDS per workgroup (limit 160 KiB)", a.k, lds);
     if (method == 3) {
-        hipFuncSetAttribute((const void *)kl_stream_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HIPCHK(h, hipFuncSetAttribute((const void *)kl_stream_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kl_stream_kernel<T, 3><<<a.ncols - a.col0, 256, lds, s>>>(a, mw, (T *)st, ldst);
     } else {
-        hipFuncSetAttribute((const void *)kl_stream_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HIPCHK(h, hipFuncSetAttribute((const void *)kl_stream_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kl_stream_kernel<T, 4><<<a.ncols - a.col0, 256, lds, s>>>(a, mw, (T *)st, ldst);
     }
+    return NNLM_OK;
 }
 
 template <int NKQ>
@@ -1517,8 +1495,9 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
             HIPCHK(h, hipMalloc(&h->klst, need));
             h->klst_bytes = need;
         }
-        if (h->prec == NNLM_PREC_F64) launch_kl_stream<double>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
-        else launch_kl_stream<float>(method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
+        const int rcs = (h->prec == NNLM_PREC_F64) ? launch_kl_stream<double>(h, method, a, h->MW, h->klst, (size_t)ld_con, h->stream)
+                                                   : launch_kl_stream<float>(h, method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
+        if (rcs != NNLM_OK) return rcs;
     }
     }
     HIPCHK(h, hipGetLastError());
@@ -1590,7 +1569,6 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // next sweep, a third of it cross-stream event latency), so they are fused instead: gram_partial also yields max|factor|
     // (no absmax pass, no memset), gram_reduce also writes the chain-wave constants of the strict sweep, and nothing waits on
     // another stream.
-    h->consts_ready = false;
     h->pack_ready = false;
     if (h->x16 && !h->sharded && !h->any_missing && method == 1 && !generic_rank(h)) {
         // The one-wavefront sweep kernel (k_sweep_q.h) leaves max|x| and the Gram partial sums of the factor it solved -- the fixed
@@ -1619,7 +1597,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
                     factor16_fold_kernel<<<(unsigned)(h->KP * h->KP / 64 + (cnt + 1023) / 1024), 1024, 0, h->stream>>>(
                         Ym, ldm, lim, h->k, h->KP, ldm, h->maxbits + 4 + h->sg_par, h->scal_exp + 1, h->Y16, smax_w, h->sg_slabs, h->sg_nslabs, h->Graw);
                 }
-                sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], (h->k + 3) / 4, h->sweepq_img);
+                sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], (h->k + 3) / 4, h->sweepq_img, 0);
                 h->pack_ready = true;
             }
             {
@@ -1644,9 +1622,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
             default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Ym, ldm, 0, lim, h->gslabs, mb); break;
             }
             prepare_factor16(h, which, mb, smax_w);
-            gram_reduce_consts_kernel<<<h->KP * h->KP / 64, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw, h->k, reg[0], reg[1], h->sweep_consts,
-                                                                             h->maxbits + 3, mb_next);
-            h->consts_ready = true; // (the strict kernel's constants; the one-wavefront kernel packs its operand image at launch)
+            gram_reduce_kernel<<<(h->KP * h->KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, h->KP, h->Graw);
+            HIPCHK(h, hipMemsetAsync(mb_next, 0, sizeof(unsigned), h->stream)); // the max word the NEXT half-step's gram_partial accumulates into
         }
         {
             ProfScope ps(h, which == 1 ? P_XPROD_H : (h->fuse_err ? P_XPROD_W_ERR : P_XPROD_W));
@@ -1902,6 +1879,7 @@ extern "C" int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const doub
 {
     if (!h || !reg || (which != 0 && which != 1) || phase < PH_A || phase > PH_C) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: bad arguments");
     if (!h->sharded) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: handle is not sharded (call nnlm_comm_init first)");
+    if (phase != PH_C) h->upk_max_for = -1; // (test hooks may have rewritten the factors since the last unpack: take the absmax pass)
     return half_step(h, which, reg, inner_max_iter, inner_rel_tol, method, false, false, phase);
 }
 
@@ -2041,7 +2019,8 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
         reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
         penalty_kernel<<<nbh, 256, 0, st>>>(h->H64, h->mpad, h->m, h->k, h->partials);
         reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
-    }
+    } else // (not recomputed: the collector must never see sums of an earlier call -- penalties() and need_pen could drift apart)
+        HIPCHK(h, hipMemsetAsync(h->scal + 2, 0, 6 * sizeof(double), st));
     HIPCHK(h, hipMemcpyAsync(h->host_res, h->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (with_sweeps) {
         const unsigned long long *src = h->sweeps + h->sw_active;
@@ -2145,6 +2124,7 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     }
     h->rank = rank;
     h->nranks = nranks;
+    h->upk_max_for = -1; // (the cached max|factor| of an unpack belongs to the previous communicator's exchange)
     h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
     {
         const char *form = getenv("NNLM_SHARD_DENSE"); // "reduce": contraction-sharded + all-reduce; default "cols": column-sharded, all-gather only

@@ -21,6 +21,11 @@
 
 #include "nnlm_mi355x.h"
 
+/* Re-raises a pending user interrupt after the handle has been released.  Declared in Rinterface.h (the Unix embedding
+ * header), not in Rinternals.h: declared here so that no platform header is needed and no implicit declaration is left
+ * for compilers that reject them. */
+extern void Rf_onintr(void);
+
 /* ---- callbacks = the R API points the reference touches (include/nnlm_mi355x.h nnlm_callbacks) ---------------- */
 static void chk_intr_body(void *dummy) { (void)dummy; R_CheckUserInterrupt(); }
 static int cb_check_interrupt(void *ctx)

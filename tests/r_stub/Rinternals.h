@@ -39,7 +39,6 @@ SEXP Rf_xlengthgets(SEXP, R_xlen_t);
 SEXP Rf_ScalarInteger(int);
 void Rf_error(const char *, ...) __attribute__((noreturn));
 void Rf_warning(const char *, ...);
-void Rf_onintr(void);
 #ifdef __cplusplus
 }
 #endif

@@ -365,3 +365,45 @@ def test_bench_multi_gpu_branch_runs_with_a_forced_one_rank_communicator(tmp_pat
         assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "strong"
     assert "all-gather" in sharded["config"]["parallelism"] and plain["config"]["parallelism"] == "1 GPU"
     assert abs(sharded["final_mse"] - plain["final_mse"]) < 1e-6 * plain["final_mse"]
+
+
+# ---- N > 1 on real hardware: runs the moment the suite lands on a box with two or more GPUs ------------------------------------
+def _gpu_count():
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs on the node (the gpurun lease has one); live on a multi-GPU box")
+@pytest.mark.parametrize("form", ["cols", "reduce"])
+def test_two_ranks_over_rccl_match_the_single_gpu_run(form):
+    """BASELINE configs[3] at two ranks, for real: bench.py --gpus 2 under torch.distributed.run (one process per GPU, RCCL over
+    xGMI) on a reduced size, both exchange forms, against the single-GPU line of the same size: same final mse (the sharded
+    half-steps reproduce the unsharded factors up to summation order), strong scaling declared, n_gpus = 2."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tail = ["--steps", "6", "--warmup", "2", "--cpu-iters", "0", "--repeats", "1", "--size", "6000,4000,50", "--others", "0"]
+    env = dict(os.environ, NNLM_SHARD_DENSE=form, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k_, None)
+
+    def last_json(cmd, environment):
+        out = subprocess.run(cmd, env=environment, capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()
+        assert out and out[-1].startswith("{"), out[-3:]
+        return json.loads(out[-1])
+
+    two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + tail, env)
+    one = last_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + tail, env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["value"] > 0
+    assert ("all-reduce" in two["config"]["parallelism"]) == (form == "reduce")
+    assert abs(two["final_mse"] - one["final_mse"]) < 1e-6 * one["final_mse"]

@@ -408,7 +408,7 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(monkeypatch, pname,
     a, b = out
     if pname == "f32":
         # the plain F32 path takes the Gram partial sums of a solved factor from the sweep kernel's LDS image (one slab per
-        # workgroup of 48 columns, k_sweep_wgf.h), the sharded path from gram_partial_kernel (256 columns per slab): the same
+        # workgroup of 64 columns, k_sweep_q.h), the sharded path from gram_partial_kernel (256 columns per slab): the same
         # products in another order of addition -- 1e-15 differences in the fp64 Gram (one half-step: 2e-15 in the factor),
         # which eight half-steps of coordinate descent amplify to ~1e-7 (scripts/gpu_sg_ab.py); the mode's parity bound is 1e-4
         assert relF(a[0], b[0]) < 1e-5 and relF(a[1], b[1]) < 1e-5 and abs(a[2] - b[2]) <= 2
@@ -480,10 +480,11 @@ def test_virtual_ranks_run_whole_sharded_half_steps(monkeypatch, pname, prec, to
     assert abs(mse - mse_ref) < 1e-9 * mse_ref if pname == "f64" else abs(mse - mse_ref) < 1e-5 * mse_ref
 
 
-# ---- the restructured SCD sweep of the f32 mode (k_sweep_wgf.h): masks, columns that finish early, ragged shapes ------
+# ---- the one-wavefront SCD sweep of the f32 mode (k_sweep_q.h): masks, columns that finish early, ragged shapes ------
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(300, 101, 9), (257, 1000, 17), (70, 50, 18), (120, 49, 33), (64, 97, 34), (130, 60, 49), (400, 530, 50),
-                                   (90, 97, 64)])  # 17/18, 33/34, 49/50: the tail-block form with 1, 2, 3 update tiles
+@pytest.mark.parametrize("shape", [(300, 101, 9), (90, 130, 13), (257, 1000, 17), (70, 50, 21), (111, 77, 26), (120, 49, 32), (64, 97, 33),
+                                   (75, 200, 38), (130, 60, 44), (60, 129, 48), (400, 530, 50), (88, 65, 53), (140, 64, 58),
+                                   (90, 97, 64)])  # k = 9 .. 64: every instantiation sweep_scd_q_kernel<NT, NB> has (NB = ceil(k / 4) = 3 .. 16)
 @pytest.mark.parametrize("inner,itol", [(50, 1e-3), (7, 1e-9), (200, 1e-6), (0, 1e-9), (1, -1.0)])
 def test_fast_sweep_with_masks_and_early_finishers(shape, inner, itol):
     n, m, k = shape
