@@ -81,7 +81,7 @@ def run_steps(h, cfg, steps, trace):
     return r
 
 
-def pmc_traffic(kernel, config=2):
+def pmc_traffic(kernel, config=2, f64=False):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this configuration
     (profiles/rNN_<tag>_cfg<config>_pmc_hbm_summary.txt; round-1 files carry no cfg part and are configuration 2;
     separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command; KiB per dispatch).  gfx950 correction
@@ -89,7 +89,8 @@ def pmc_traffic(kernel, config=2):
     bench.py cannot attach rocprofv3 to itself: (None, None) when no summary holding the kernel is committed."""
     import glob, re
     files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.txt"))
-             if f"_cfg{config}_" in os.path.basename(f) or ("_cfg" not in os.path.basename(f) and config == 2)]
+             if (f"_cfg{config}_" in os.path.basename(f) or ("_cfg" not in os.path.basename(f) and config == 2))
+             and (("_f64_" in os.path.basename(f)) == f64)]  # (strict-mode summaries carry _f64_ in their name)
     files.sort(key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v10 after r01_v9, r02 after r01
     for path in reversed(files):
         fetch = write = None
@@ -177,7 +178,8 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                     note += (" (fp64 vector peak) + 2k^2 per missing entry for the per-column Grams ("
                              + ("3 split-fp16 products per flop on v_mfma_f32_16x16x32_f16: a third of the 2.5 PF dense fp16 peak" if s == 4 else "fp64 MFMA peak")
                              + "); peak = total flops / (sum of the two floors)")
-                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12, pmc=None, note=note)
+                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12,
+                                   pmc=(None if cfg["na"] else "sweep_scd_q_kernel"), note=note)
     else:
         for nm in ("sweep_h", "sweep_w"):
             if kern[nm]["ms_per_launch"]:
@@ -197,7 +199,7 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
         c = classes[nm]
         ms_l = kern[nm]["ms_per_launch"]
         ach = c["work"] / (ms_l * 1e-3) / c["scale"]
-        traffic, src = (pmc_traffic(c["pmc"], config_id) if (c["pmc"] and world == 1) else (None, None))
+        traffic, src = (pmc_traffic(c["pmc"], config_id, s == 8) if (c["pmc"] and world == 1) else (None, None))
         b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
                  traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
         if "note" in c:
