@@ -4,6 +4,7 @@
 // #define SWEEPQ_DEBUG 1  (debug dumps: DUMP=col)
 #include "../../nnlm_amd/csrc/k_sweep.h"
 #include "../../nnlm_amd/csrc/k_sweep_q.h"
+#include "k_sweep_q20.h" // (experiment only, not part of the product: 16 + 4 columns per wavefront -- measured, no gain)
 #include <cstdio>
 #include <cmath>
 #include <vector>
@@ -16,7 +17,7 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
     const int ld = (ncols + 255) / 256 * 256;
     const double r0 = 0.02, r1 = 0.01, r2 = 0.03;
     const double tol = getenv("REL_TOL") ? atof(getenv("REL_TOL")) : 1e-9;
-    const bool masked = getenv("MASK") != nullptr;
+    const bool masked = getenv("MASK") != nullptr, q20 = getenv("Q20") != nullptr;
     std::mt19937_64 rng(1);
     std::uniform_real_distribution<double> U(0, 1);
     const int nsl = getenv("SLABS") ? atoi(getenv("SLABS")) : 1;
@@ -30,9 +31,9 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
             for (int q = 0; q < k; q++) if (U(rng) < 0.15) M[c] |= 1ull << q;
             if (c % 97 == 5) M[c] = ~0ull;
         }
-    double *dG, *dX, *dC, *dO1, *dO2, *dI; unsigned long long *dS, *dM;
+    double *dG, *dX, *dC, *dO1, *dO2, *dI, *dIB; unsigned long long *dS, *dM;
     CK(hipMalloc(&dG, G.size() * 8)); CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dC, C.size() * 8 * nsl)); CK(hipMalloc(&dS, 16)); CK(hipMalloc(&dM, M.size() * 8));
-    CK(hipMalloc(&dO1, X.size() * 8)); CK(hipMalloc(&dO2, X.size() * 8)); CK(hipMalloc(&dI, sweepq_img_doubles(NB) * 8));
+    CK(hipMalloc(&dO1, X.size() * 8)); CK(hipMalloc(&dO2, X.size() * 8)); CK(hipMalloc(&dI, sweepq_img_doubles(NB, false) * 8)); CK(hipMalloc(&dIB, sweepq20_img_doubles(NB) * 8));
     CK(hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice));
     {
         std::vector<double> Cs(C.size());
@@ -49,7 +50,7 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
     float *dOp = nullptr;
     if (getenv("OP")) { CK(hipMalloc(&dOp, (size_t)ld * KP * 4)); a.op = dOp; a.op_mode = 2; a.op_ld = KP; a.op_f64 = 0; }
     if (getenv("GRAM")) {
-        const int nwg = (ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
+        const int nwg = (ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1;
         CK(hipMalloc(&a.gram_slabs, (size_t)nwg * KP * KP * 8));
         CK(hipMalloc(&a.maxbits, 4)); CK(hipMemset(a.maxbits, 0, 4));
     }
@@ -60,11 +61,13 @@ template <int NT, int NB> static int run(int ncols, int k, int max_iter)
         a.Xout = dO2;
         CK(hipMemset(dS, 0, 16));
         hipEventRecord(e0);
-        sweepq_pack_kernel<<<8, 256>>>(dG, KP, k, a.r0, a.r1, NB, dI);
+        sweepq_pack_kernel<<<8, 256>>>(dG, KP, k, a.r0, a.r1, NB, dI, 0);
         hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&msp, e0, e1);
+        if (q20) sweepq20_pack_kernel<<<8, 256>>>(dG, KP, k, a.r0, a.r1, NB, dIB);
         hipEventRecord(e0);
-        if (masked) sweep_scd_q_kernel<NT, NB, true><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
-        else sweep_scd_q_kernel<NT, NB, false><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
+        if (q20) sweep_scd_q20_kernel<NT, NB><<<(ncols + SWEEPQ20_COLS - 1) / SWEEPQ20_COLS, SWEEPQ_THREADS>>>(a, dI, dIB);
+        else if (masked) sweep_scd_q_kernel<NT, NB, true, false><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
+        else sweep_scd_q_kernel<NT, NB, false, false><<<(ncols + SWEEPQ_COLS - 1) / SWEEPQ_COLS, SWEEPQ_THREADS>>>(a, dI);
         hipEventRecord(e1); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms2, e0, e1);
     }
     CK(hipGetLastError());
