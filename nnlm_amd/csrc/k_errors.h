@@ -14,6 +14,11 @@
 // instructions: x = m 2^e with m in [sqrt(1/2), sqrt 2), ln m = 2 atanh(s), s = (m - 1) / (m + 1) (|s| <= 0.1716: ten terms of the
 // odd series leave 6e-19), the quotient correctly rounded (reciprocal, two Newton steps, one residual correction).  libm's log()
 // compiles to ~55 instructions here and was two thirds of errors_kernel<double>'s arithmetic.  Error < 2 ulp of the result.
+// (The series coefficients live in constant memory, NOT as literals: gfx950's VOP3 encoding has no 64-bit literal operand, so each
+// literal costs a VGPR pair -- 30 registers of a kernel that needs them for occupancy; loaded from a non-const __constant__ array
+// they arrive by s_load and stay in SGPR pairs, one scalar source per fma.)
+static __constant__ double NNLM_LOGC[12] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0,
+                                            1.0 / 5.0,  1.0 / 3.0,  1.9082149292705877e-10, 0.693147180369123816490};
 __device__ static inline double nnlm_log_pos(double x)
 {
     double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
@@ -28,20 +33,13 @@ __device__ static inline double nnlm_log_pos(double x)
     double sq = num * r;
     sq = __builtin_fma(__builtin_fma(-den, sq, num), r, sq);
     const double z = sq * sq;
-    double p = 1.0 / 21.0;
-    p = __builtin_fma(p, z, 1.0 / 19.0);
-    p = __builtin_fma(p, z, 1.0 / 17.0);
-    p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, 1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, 1.0 / 3.0);
+    double p = NNLM_LOGC[0];
+#pragma unroll
+    for (int c = 1; c < 10; c++) p = __builtin_fma(p, z, NNLM_LOGC[c]);
     // ln m = 2 s + 2 s z p;  e ln 2 in two pieces (the high one has 11 trailing zero bits: e * LN2_HI is exact for |e| < 2048)
     const double ed = (double)e;
-    const double t = __builtin_fma(2.0 * sq * z, p, ed * 1.9082149292705877e-10);
-    return __builtin_fma(ed, 0.693147180369123816490, 2.0 * sq + t);
+    const double t = __builtin_fma(2.0 * sq * z, p, ed * NNLM_LOGC[10]);
+    return __builtin_fma(ed, NNLM_LOGC[11], 2.0 * sq + t);
 }
 
 // partial: [gridDim.y*gridDim.x][2] = {sum (a-ahat)^2, sum -(a+eps)log(ahat+eps)+ahat} over valid entries
@@ -123,6 +121,228 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
         const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         partial[2 * blk] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
         partial[2 * blk + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strict fp64 mode, ranks <= 64: the same two sums with the factor slices staged in LDS and the per-entry arithmetic branch free.
+// (errors_kernel<double> above: 0.90 ms at config 2 -- its lanes fetched every MFMA operand from global memory, 3.2x the bytes of
+// the A tile, and the `if (valid)` regions made the compiler rematerialise the log's 20 constant registers per entry:
+// 1880 VALU instructions per wavefront for 16 entries per lane.)
+//   * a block of 4 wavefronts owns one 64-row i-tile and walks a chunk of j-tiles: the k x 64 slice of W goes to LDS once, the
+//     k x 64 slice of H once per tile (global_load_lds, two 512-byte rows per instruction; the two 128-byte halves of odd rows
+//     are exchanged on the SOURCE side so that a half-wave's operand read -- rows kq, kq+1, sixteen consecutive columns each --
+//     covers all 64 banks);
+//   * per tile: [H slice + A tile landed, barrier] 13 x 4 v_mfma_f64_16x16x4 per wavefront (32 x 32 entries) [barrier] the next
+//     H slice and the next A tile are requested, and stay in flight while the 16 entries per lane of this tile are summed;
+//   * two (k <= 52: three) blocks per CU drift out of phase: one block's matrix phase runs beside the other's logarithms;
+//   * edge tiles and missing entries (MASKED, block-uniform choice per tile) select 0 instead of branching.
+// Bound: 2 n m k fp64 matrix flops (0.254 ms at 78.6 TF for config 2) + ~40 fp64 VALU slots per entry (0.2 ms) on the same
+// pipes, against 1.6 GB of A (0.2 ms).
+// partial: [gridDim.x][2].  Grid: nit * nchunks blocks, i-tile fastest (neighbouring blocks share the H slices in L2).
+// ------------------------------------------------------------------------------------------------
+#define ERR64_THREADS 256
+#ifndef ERR64_WPS
+#define ERR64_WPS 2
+#endif
+#ifndef ERR64_UNROLL
+#define ERR64_UNROLL 2
+#endif
+#define ERR64_HR 8 // 16-byte pieces of a slice per lane: ranks up to 64
+#ifndef ERR64_EXP
+#define ERR64_EXP 0 // ablation switches of scripts/exp/err64_exp.hip only: 1 no sums, 2 no matrix phase, 4 no A loads
+#endif
+__host__ __device__ static inline int errors64_lds_bytes(int k4) { return 3 * k4 * 512; }
+
+template <bool MASKED>
+__device__ __forceinline__ void errors64_sums(const f64x4 (&acc)[2][2], const double (&av)[2][2][4], const uint32_t (&mw)[2][4], int ivalid,
+                                              int jvalid, int l15, int lg, double &s2, double &skl)
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double ah = acc[a][b][r], aa = av[a][b][r];
+                const double d = aa - ah;
+                const double lg_ = nnlm_log_pos(ah + NNLM_TINY);
+                const double term = __builtin_fma(-(aa + NNLM_TINY), lg_, ah);
+                if constexpr (MASKED) {
+                    const bool valid = (16 * a + l15 < ivalid) && (16 * b + lg + 4 * r < jvalid) && !((mw[b][r] >> (16 * a + l15)) & 1u);
+                    s2 += valid ? d * d : 0.0;
+                    skl += valid ? term : 0.0;
+                } else {
+                    s2 = __builtin_fma(d, d, s2);
+                    skl += term;
+                }
+            }
+}
+
+template <bool HAS_MISS>
+__global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(const double *__restrict__ A, int lda, const uint32_t *__restrict__ miss,
+                                                                    const double *__restrict__ W64, int ldw, const double *__restrict__ H64,
+                                                                    int ldh, int n, int m, int k4, double *__restrict__ partial, int jt0,
+                                                                    int jcnt, int chunk, int nit)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_e64[];
+    const int slice_bytes = k4 * 512;
+    unsigned char *Ws = smem_e64, *Hs = smem_e64 + slice_bytes; // Hs: two buffers
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int it = blockIdx.x % nit, ch = blockIdx.x / nit;
+    const int i0 = it * ERR_TILE;
+    const int jt_begin = jt0 + ch * chunk;
+    const int jt_end = (jt_begin + chunk < jt0 + jcnt) ? jt_begin + chunk : jt0 + jcnt;
+    const int ib = 32 * (wave & 1), jb = 32 * (wave >> 1);
+    const int nch = k4 >> 1; // 1 KiB pieces (two rows) per slice; piece t belongs to wavefront t & 3
+    const int words = lda >> 5;
+
+    // k4 x 64 slice of a factor, columns [c0, c0 + 64), through registers (ERR64_HR x 16 bytes per lane).  Every request of this
+    // kernel is an ordinary load the compiler's wait-count pass can see and count: with LDS-DMA in the queue (invisible when
+    // written out, a full wait in front of every LDS read when not) its counted waits for the A tile forced part of the NEXT
+    // tile to land.  Piece = rows 2t (lanes 0..31) and 2t+1 (lanes 32..63), 16 bytes per lane, odd rows with their 128-byte halves
+    // exchanged (see above).
+    const int half = lane >> 5;
+    const int lbyte = ((lane & 31) * 16) ^ (half << 7);
+    auto slice_load = [&](const double *X, int ld, int c0, f32x4 (&hr)[ERR64_HR]) {
+#pragma unroll
+        for (int u = 0; u < ERR64_HR; u++) {
+            const int t = (wave + 4 * u < nch) ? wave + 4 * u : nch - 1; // (clamped, not skipped: a conditional load is sunk to its use)
+            hr[u] = *(const f32x4 *)((const unsigned char *)(X + (size_t)(2 * t + half) * ld + c0) + lbyte);
+        }
+    };
+    auto slice_store = [&](unsigned char *dst, const f32x4 (&hr)[ERR64_HR]) {
+#pragma unroll
+        for (int u = 0; u < ERR64_HR; u++) {
+            const int t = wave + 4 * u;
+            if (t < nch) *(f32x4 *)(dst + t * 1024 + lane * 16) = hr[u];
+        }
+    };
+    auto tile_a = [&](int jt, double (&av)[2][2][4], uint32_t (&mw)[2][4]) {
+        if constexpr (HAS_MISS) {
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mw[b][r] = miss[(size_t)(jt * ERR_TILE + jb + 16 * b + lg + 4 * r) * words + ((i0 + ib) >> 5)];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    av[a][b][r] = (ERR64_EXP & 4) ? 0.5 : A[(size_t)(jt * ERR_TILE + jb + 16 * b + lg + 4 * r) * lda + i0 + ib + 16 * a + l15];
+    };
+
+    double s2 = 0.0, skl = 0.0;
+    double av0[2][2][4], av1[2][2][4];
+    uint32_t mw0[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, mw1[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 hr[ERR64_HR];
+#pragma unroll
+    for (int u = 0; u < ERR64_HR; u++) hr[u] = f32x4{0, 0, 0, 0};
+    if (jt_begin < jt_end) {
+        f32x4 wr[ERR64_HR];
+#pragma unroll
+        for (int u = 0; u < ERR64_HR; u++) wr[u] = f32x4{0, 0, 0, 0};
+        slice_load(W64, ldw, i0, wr);
+        slice_load(H64, ldh, jt_begin * ERR_TILE, hr);
+        tile_a(jt_begin, av0, mw0);
+        slice_store(Ws, wr);
+        slice_store(Hs, hr);
+    }
+    const int swz = (lg & 1) << 7;
+    const unsigned char *wrow = Ws + lg * 512;
+    const int wo0 = ((ib + l15) * 8) ^ swz, wo1 = ((ib + 16 + l15) * 8) ^ swz;
+    const int ho0 = ((jb + l15) * 8) ^ swz, ho1 = ((jb + 16 + l15) * 8) ^ swz;
+    const bool iedge = i0 + ERR_TILE > n;
+
+    // One tile: [the slices written at the end of the last tile are visible] barrier [H slice of the next tile requested into
+    // registers] matrix phase [A of the next tile requested] sums [the H registers go to the other LDS buffer].  The loads of A get
+    // the sums of one tile and the matrix phase of the next (~6500 cycles) to arrive, the H slice a whole tile.
+    auto tile = [&](int jt, int buf, double (&av)[2][2][4], uint32_t (&mw)[2][4], double (&avn)[2][2][4], uint32_t (&mwn)[2][4]) {
+        const int jn = (jt + 1 < jt_end) ? jt + 1 : jt; // (unconditional requests: a conditional load is a phi, and the phi a copy behind a full wait)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(ERR64_EXP & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(ERR64_EXP & 8)) slice_load(H64, ldh, jn * ERR_TILE, hr);
+        const unsigned char *hrow = Hs + buf * slice_bytes + lg * 512;
+        f64x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0, 0, 0, 0};
+        // Matrix phase, operands two sets deep: the four LDS reads of step s+1 are in flight while the four MFMAs of step s
+        // issue.  Reads and waits are written out and pinned (left to the compiler, the loop is rotated back into read -> wait ->
+        // use, one LDS latency per step: 116 instead of 64 cycles per MFMA); the two sets keep their names (no copies of
+        // registers a read is still in flight to).
+        const unsigned wad = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)wrow;
+        const unsigned had = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)hrow;
+        const unsigned aw0 = wad + wo0, aw1 = wad + wo1, ah0 = had + ho0, ah1 = had + ho1;
+        double pw0, pw1, ph0, ph1, qw0, qw1, qh0, qh1;
+#define E64_READ(w0_, w1_, h0_, h1_, step)                                                                                              \
+    {                                                                                                                                 \
+        const unsigned o_ = (unsigned)(step) * 2048u;                                                                                 \
+        if (!(ERR64_EXP & 16) || (step) == 0)                                                                                         \
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"                          \
+                     : "=&v"(w0_), "=&v"(w1_), "=&v"(h0_), "=&v"(h1_)                                                                   \
+                     : "v"(aw0 + o_), "v"(aw1 + o_), "v"(ah0 + o_), "v"(ah1 + o_)                                                      \
+                     : "memory");                                                                                                     \
+    }
+#define E64_MMA(w0_, w1_, h0_, h1_, cnt)                                                                                               \
+    {                                                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(w0_), "+v"(w1_), "+v"(h0_), "+v"(h1_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(h0_, w0_, acc[0][0], 0, 0, 0); /* M = column j, N = row i */                  \
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(h0_, w1_, acc[1][0], 0, 0, 0);                                               \
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(h1_, w0_, acc[0][1], 0, 0, 0);                                               \
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(h1_, w1_, acc[1][1], 0, 0, 0);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    }
+        const int ns = ((ERR64_EXP & 2) ? 4 : k4) >> 2; // k steps of 4
+        const int nl = ns - 1;
+        double rw0, rw1, rh0, rh1;
+        E64_READ(pw0, pw1, ph0, ph1, 0);
+        E64_READ(qw0, qw1, qh0, qh1, (1 < nl) ? 1 : nl);
+        int st = 0;
+        for (; st + 3 <= ns; st += 3) { // (three sets: a read into a set is two MFMA groups behind the group that used it)
+            E64_READ(rw0, rw1, rh0, rh1, (st + 2 < nl) ? st + 2 : nl);
+            E64_MMA(pw0, pw1, ph0, ph1, 8);
+            E64_READ(pw0, pw1, ph0, ph1, (st + 3 < nl) ? st + 3 : nl);
+            E64_MMA(qw0, qw1, qh0, qh1, 8);
+            E64_READ(qw0, qw1, qh0, qh1, (st + 4 < nl) ? st + 4 : nl);
+            E64_MMA(rw0, rw1, rh0, rh1, 8);
+        }
+        if (st < ns) E64_MMA(pw0, pw1, ph0, ph1, 4);
+        if (st + 1 < ns) E64_MMA(qw0, qw1, qh0, qh1, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (redundant last reads)
+#undef E64_READ
+#undef E64_MMA
+        tile_a(jn, avn, mwn);
+        const bool masked = HAS_MISS || iedge || ((jt + 1) * ERR_TILE > m); // block uniform
+        if (ERR64_EXP & 1) s2 += acc[0][0][0] + acc[1][1][3] + acc[0][1][1] + acc[1][0][2] + av[0][0][0] + av[1][1][3];
+        else if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl);
+        else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl);
+        slice_store(Hs + (1 - buf) * slice_bytes, hr);
+    };
+    int jt = jt_begin;
+    for (; jt + 1 < jt_end; jt += 2) { // (pairs: the two register sets of A keep their names, no copies)
+        tile(jt, 0, av0, mw0, av1, mw1);
+        tile(jt + 1, 1, av1, mw1, av0, mw0);
+    }
+    if (jt < jt_end) tile(jt, 0, av0, mw0, av1, mw1);
+
+    __shared__ double red64[2][4];
+    s2 = wave_sum(s2);
+    skl = wave_sum(skl);
+    if (lane == 0) {
+        red64[0][wave] = s2;
+        red64[1][wave] = skl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * (size_t)blockIdx.x] = ((red64[0][0] + red64[0][1]) + red64[0][2]) + red64[0][3];
+        partial[2 * (size_t)blockIdx.x + 1] = ((red64[1][0] + red64[1][1]) + red64[1][2]) + red64[1][3];
     }
 }
 
@@ -385,21 +605,32 @@ __global__ __launch_bounds__(256) void penalty_kernel(const double *__restrict__
     }
 }
 
-// out[c] = sum_b partial[b*width + c], fixed order (one block of 256 threads).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partial, size_t nblocks, int width,
-                                                              double *__restrict__ out)
+// out[c] = sum_b partial[b*width + c], fixed order (one block of REDUCE_THREADS threads, four loads in flight per thread: the
+// error kernels leave up to 5e4 partial pairs behind; one 256-thread block with one load at a time took 0.29 ms for them).
+#define REDUCE_THREADS 1024
+__global__ __launch_bounds__(REDUCE_THREADS) void reduce_partials_kernel(const double *__restrict__ partial, size_t nblocks, int width,
+                                                                         double *__restrict__ out)
 {
-    __shared__ double red[256];
+    __shared__ double red[REDUCE_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = 0; c < width; c++) {
-        double s = 0.0;
-        for (size_t b = threadIdx.x; b < nblocks; b += 256) s += partial[b * width + c];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        size_t b = threadIdx.x;
+        for (; b + 3 * REDUCE_THREADS < nblocks; b += 4 * REDUCE_THREADS) {
+            s0 += partial[b * width + c];
+            s1 += partial[(b + REDUCE_THREADS) * width + c];
+            s2 += partial[(b + 2 * REDUCE_THREADS) * width + c];
+            s3 += partial[(b + 3 * REDUCE_THREADS) * width + c];
         }
-        if (threadIdx.x == 0) out[c] = red[0];
+        for (; b < nblocks; b += REDUCE_THREADS) s0 += partial[b * width + c];
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < REDUCE_THREADS / 64; w++) t += red[w];
+            out[c] = t;
+        }
         __syncthreads();
     }
 }

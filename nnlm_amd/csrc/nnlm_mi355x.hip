@@ -1968,7 +1968,7 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
     if (fused_nb > 0) {
         ProfScope ps(h, P_ERRORS, st);
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_xdone, 0));
-        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)fused_nb, 2, h->scal);
+        reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, (size_t)fused_nb, 2, h->scal);
     } else {
         ProfScope ps(h, P_ERRORS, st);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
@@ -1981,6 +1981,25 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
         const int jcnt = h->sharded ? ((jt0 + per < tj ? jt0 + per : tj) - jt0) : tj;
         if (jcnt <= 0) {
             nb = 0;
+        } else if (h->prec == NNLM_PREC_F64 && !generic_rank(h)) {
+            // one 64-row i-tile x a chunk of j-tiles per block; ~8 rounds of the 2 x 256 resident blocks
+            const int nit = h->npad / ERR_TILE;
+            int nchunks = (8 * 512 + nit / 2) / nit;
+            if (nchunks < 1) nchunks = 1;
+            if (nchunks > jcnt) nchunks = jcnt;
+            const int chunk = (jcnt + nchunks - 1) / nchunks;
+            nchunks = (jcnt + chunk - 1) / chunk;
+            nb = (size_t)nit * nchunks;
+            const int lds = errors64_lds_bytes(k4);
+            if (miss) {
+                hipFuncSetAttribute((const void *)errors64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                errors64_kernel<true><<<(unsigned)nb, ERR64_THREADS, lds, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n,
+                                                                                h->m, k4, h->partials, jt0, jcnt, chunk, nit);
+            } else {
+                hipFuncSetAttribute((const void *)errors64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                errors64_kernel<false><<<(unsigned)nb, ERR64_THREADS, lds, st>>>((const double *)h->A, h->npad, nullptr, h->W64, h->npad, h->H64, h->mpad,
+                                                                                 h->n, h->m, k4, h->partials, jt0, jcnt, chunk, nit);
+            }
         } else if (h->prec == NNLM_PREC_F64) {
             dim3 grid(h->npad / ERR_TILE, jcnt);
             nb = (size_t)grid.x * grid.y;
@@ -2007,7 +2026,7 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
                                                                  h->n, h->m, k2, h->partials, jt0, nx);
             }
         }
-        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, nb, 2, h->scal);
+        reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, nb, 2, h->scal);
         if (h->sharded && h->comm) {
             ncclResult_t r = g_rccl.AllReduce(h->scal, h->scal, 2, ncclDouble, ncclSum, (ncclComm_t)h->comm, st);
             if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (error sums) failed");
@@ -2016,9 +2035,9 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
     if (need_pen) {
         const int nbw = (h->n + 255) / 256, nbh = (h->m + 255) / 256;
         penalty_kernel<<<nbw, 256, 0, st>>>(h->W64, h->npad, h->n, h->k, h->partials);
-        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
+        reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, (size_t)nbw, 3, h->scal + 2);
         penalty_kernel<<<nbh, 256, 0, st>>>(h->H64, h->mpad, h->m, h->k, h->partials);
-        reduce_partials_kernel<<<1, 256, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
+        reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, (size_t)nbh, 3, h->scal + 5);
     } else // (not recomputed: the collector must never see sums of an earlier call -- penalties() and need_pen could drift apart)
         HIPCHK(h, hipMemsetAsync(h->scal + 2, 0, 6 * sizeof(double), st));
     HIPCHK(h, hipMemcpyAsync(h->host_res, h->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
