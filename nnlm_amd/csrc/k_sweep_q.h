@@ -127,15 +127,66 @@ constexpr SqSched sq_sched(int NL)
     return s;
 }
 
-// NT: the caller's rank padding KP = 16 NT (layout of the outputs and of the Gram slabs); NB = ceil(k / 4) blocks
+// What every sweep workgroup leaves behind from its final x image xl[COLS][KP + 2] (columns col_base .. col_base + COLS - 1): the
+// factor outputs, max|x| and the Gram partial sums of its columns (slab `slab_idx`) for the next half-step.
+template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(const SweepArgs &a, const double *xl, int col_base, int slab_idx)
+{
+    constexpr int KP = 16 * NT, XS = KP + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
+    float xmax = 0.0f;
+    for (int e = tid; e < COLS * KP; e += SWEEPQ_THREADS) {
+        const int q = e / COLS, c = e % COLS, ecol = col_base + c;
+        if (q < k && ecol < a.ncols) {
+            const double xv = xl[c * XS + q];
+            xmax = fmaxf(xmax, fabsf((float)xv));
+            a.Xout[(size_t)q * a.ldo + (ecol - a.ocol0)] = xv;
+            if (a.op_mode == 1) {
+                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + ecol] = xv;
+                else ((float *)a.op)[(size_t)q * a.op_ld + ecol] = (float)xv;
+            }
+        }
+    }
+    if (a.maxbits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
+    }
+    if (a.gram_slabs) {
+        // Gram partial sums of this workgroup's columns, X X^T over the COLS columns with v_mfma_f64_16x16x4_f64, upper tiles dealt
+        // to the four wavefronts, slab layout of gram_partial_kernel (k_gram.h); folded by factor16_fold_kernel (fence-free)
+        const int l15 = lane & 15, lg = lane >> 4;
+        double *slab = a.gram_slabs + (size_t)slab_idx * KP * KP;
+        int tix = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+            for (int tb = ta; tb < NT; tb++) {
+                if ((tix++ & 3) != wave) continue;
+                f64x4 g = f64x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < COLS / 4; s4++) {
+                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = g[r];
+            }
+    }
+}
+
+// LDS of one 16-column-per-wavefront workgroup: the x image and the operand image
+__host__ __device__ static inline size_t sweepq_lds_bytes(int KP, int NB, bool strict) { return ((size_t)SWEEPQ_COLS * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32) * 8; }
+
+// NT: the caller's rank padding KP = 16 NT (layout of the outputs and of the Gram slabs); NB = ceil(k / 4) blocks.
+// Workgroup blockIdx.x of the launch.  (A device function + sweepq_epilogue: scripts/exp/k_sweep_q4.h mixes it with a second
+// workgroup shape in one launch -- measured, not taken.)
 template <int NT, int NB, bool HAS_MASK, bool STRICT>
-// (masked with k > 56: one wavefront per SIMD rather than spills)
-__global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && NB >= 15) ? 1 : 2)) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
+__device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *__restrict__ img, unsigned char *smem)
 {
     constexpr int KP = 16 * NT, NP = (NB + (STRICT ? 4 : 2)) / 2, XS = KP + 2;
     static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 1, "NB = ceil(k / 4)");
-    __shared__ __attribute__((aligned(16))) double xl[SWEEPQ_COLS * XS]; // x[column][coordinate], final values
-    __shared__ __attribute__((aligned(16))) double opl[NB * NP * 32];    // the operand image
+    double *xl = (double *)smem;       // [SWEEPQ_COLS][XS]: x[column][coordinate], final values
+    double *opl = xl + SWEEPQ_COLS * XS; // [NB * NP * 32]: the operand image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ri = lane >> 4, c16 = lane & 15; // row of the lane's coordinates inside their blocks; column inside the wavefront
     const int k = a.k;
@@ -333,47 +384,17 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && NB >= 15) ? 1 : 2)) v
     if (act) write_col();
     __syncthreads(); // x image final
 
-    float xmax = 0.0f;
-    for (int e = tid; e < SWEEPQ_COLS * KP; e += SWEEPQ_THREADS) {
-        const int q = e / SWEEPQ_COLS, c = e % SWEEPQ_COLS, ecol = col_base + c;
-        if (q < k && ecol < a.ncols) {
-            const double xv = xl[c * XS + q];
-            xmax = fmaxf(xmax, fabsf((float)xv));
-            a.Xout[(size_t)q * a.ldo + (ecol - a.ocol0)] = xv;
-            if (a.op_mode == 1) {
-                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + ecol] = xv;
-                else ((float *)a.op)[(size_t)q * a.op_ld + ecol] = (float)xv;
-            }
-        }
-    }
-    if (a.maxbits) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
-        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
-    }
-    if (a.gram_slabs) {
-        // Gram partial sums of this workgroup's columns, X X^T over the 64 columns with v_mfma_f64_16x16x4_f64, upper tiles dealt
-        // to the four wavefronts, slab layout of gram_partial_kernel (k_gram.h); folded by factor16_fold_kernel (fence-free)
-        const int l15 = lane & 15, lg = lane >> 4;
-        double *slab = a.gram_slabs + (size_t)blockIdx.x * KP * KP;
-        int tix = 0;
-#pragma unroll
-        for (int ta = 0; ta < NT; ta++)
-#pragma unroll
-            for (int tb = ta; tb < NT; tb++) {
-                if ((tix++ & 3) != wave) continue;
-                f64x4 g = f64x4{0, 0, 0, 0};
-#pragma unroll
-                for (int s4 = 0; s4 < SWEEPQ_COLS / 4; s4++) {
-                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = g[r];
-            }
-    }
+    sweepq_epilogue<NT, SWEEPQ_COLS>(a, xl, col_base, (int)blockIdx.x);
     {
         const long long tot = wave_sum_ll((ri == 0) ? (long long)t_lane : 0ll);
         if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
     }
+}
+
+// (masked with k > 56: one wavefront per SIMD rather than spills)
+template <int NT, int NB, bool HAS_MASK, bool STRICT>
+__global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && NB >= 15) ? 1 : 2)) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sq_smem[]; // sweepq_lds_bytes(KP, NB, STRICT)
+    sweepq16_body<NT, NB, HAS_MASK, STRICT>(a, img, sq_smem);
 }

@@ -951,14 +951,20 @@ static int sweep_lanes_per_column(int ncols)
 // fp64 mode: the reference's arithmetic (correctly rounded mu / G[q][q]).
 static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX; }
 
+template <int NT, int NB, bool M, bool S> static void launch_sweep_q_k(nnlm_handle *h, const SweepArgs &a, int nb)
+{
+    const int lds = (int)sweepq_lds_bytes(16 * NT, NB, S); // x image + operand image (up to 75 KB at k = 64)
+    hipFuncSetAttribute((const void *)sweep_scd_q_kernel<NT, NB, M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    sweep_scd_q_kernel<NT, NB, M, S><<<nb, SWEEPQ_THREADS, lds, h->stream>>>(a, h->sweepq_img);
+}
 template <int NT, int NB> static void launch_sweep_q_m(nnlm_handle *h, const SweepArgs &a, int nb)
 {
     if (h->prec == NNLM_PREC_F64) {
-        if (a.mask) sweep_scd_q_kernel<NT, NB, true, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
-        else sweep_scd_q_kernel<NT, NB, false, true><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+        if (a.mask) launch_sweep_q_k<NT, NB, true, true>(h, a, nb);
+        else launch_sweep_q_k<NT, NB, false, true>(h, a, nb);
     } else {
-        if (a.mask) sweep_scd_q_kernel<NT, NB, true, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
-        else sweep_scd_q_kernel<NT, NB, false, false><<<nb, SWEEPQ_THREADS, 0, h->stream>>>(a, h->sweepq_img);
+        if (a.mask) launch_sweep_q_k<NT, NB, true, false>(h, a, nb);
+        else launch_sweep_q_k<NT, NB, false, false>(h, a, nb);
     }
 }
 static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
