@@ -553,6 +553,12 @@ __device__ static inline float kl_wave_total(float v)
     return v;
 }
 #define KLT_THREADS 512
+#ifndef KLT_PBD
+#define KLT_PBD 5 // pass B: row elements requested this many chunks ahead
+#endif
+#ifndef KLT_EXP
+#define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests, 4 no pass B, 8 no pass A
+#endif
 // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the vector-memory queue, i.e. wait for the
 // row prefetch (LDS-DMA) at every coordinate step.  Each wavefront reads back only LDS slots its own LDS-DMA wrote, after its
 // own s_waitcnt vmcnt, so the barrier has nothing to order there.
@@ -611,6 +617,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)sp);
         const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
         // (only slots of the LAST piece can lie beyond the end of the arrays: L4 >= 512 (EPT4 - 1) + 64 wave whenever that piece exists)
+        if ((KLT_EXP & 2) && q > 1) return;
         if (e + 1 < EPT4 || e * KLT_THREADS + wave * 64 + lane < L4)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(su), "s"(du) : "memory");
     };
@@ -684,10 +691,9 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             bool m_l = false;
             if (a.mask) m_l = (mks[lc * a.mw + (q >> 6)] >> (q & 63)) & 1ull; // (LDS copy: a global load here would drain the row prefetch)
             const bool doq_l = run_l && !m_l;
-            if ((__ballot(doq_l) & cmask) == 0ull) { // no column of the block visits this coordinate
-                issue(qn, nbuf);
-                continue;
-            }
+            // (a coordinate that no column of the block visits -- masks only -- takes the step with coefficients 0: a `continue` here
+            //  is a second path into the loop latch, and the compiler then writes every updated state chunk to a NEW register and
+            //  copies 80 registers back per step)
             const double xq_l = xs[lc * k + q]; // read BEFORE the barrier: wavefront 0 rewrites it after
             f32x4 acc[C][NV];
 #pragma unroll
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     issue_piece(qn, nbuf, e);
                     const f32x4 w = wq[e & 1];
 #pragma unroll
-                    for (int c = 0; c < C; c++) {
+                    for (int c = 0; c < ((KLT_EXP & 8) ? 0 : C); c++) {
                         f32x4 r;
                         r[0] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][0]));
                         r[1] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][1]));
@@ -731,9 +737,18 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     const float t = kl_wave_total((acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]));
                     if (lane == 63) red[((par * C + c) * NV + v) * 8 + wave] = t;
                 }
-            KLT_BARRIER();
+            // Lee: the denominator (src/base_algorithms.cpp:142) does not depend on this step's sums -- its reciprocal is formed in
+            // front of the barrier, and only  sum * rd, (tmp - 1) x  remain between the barrier and pass B
+            double rd4 = 0.0;
+            if (METHOD == 4) {
+                const double den = sws[lc * k + q] + a.r0 * xq_l + a.r1 * (S_l - xq_l) + a.r2; // :142
+                rd4 = __builtin_amdgcn_rcp(den);
+                rd4 = __builtin_fma(__builtin_fma(-den, rd4, 1.0), rd4, rd4);
+            }
+            if (!(KLT_EXP & 1)) KLT_BARRIER();
             float coef_l = 0.f;
-            {
+            if (KLT_EXP & 1) coef_l = 1e-12f * (acc[0][0][0] + acc[C - 1][NV - 1][3]);
+            else {
                 double sv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
@@ -742,10 +757,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 }
                 const double sw = sws[lc * k + q];
                 if (METHOD == 4) {
-                    const double den = sw + a.r0 * xq_l + a.r1 * (S_l - xq_l) + a.r2; // :142
-                    double rd = __builtin_amdgcn_rcp(den);
-                    rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
-                    const double tmp = sv[0] * rd;
+                    const double tmp = sv[0] * rd4;
                     const double d = (tmp - 1) * xq_l; // :143
                     if (doq_l) {
                         coef_l = (float)d;
@@ -776,13 +788,18 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             par ^= 1;
             { // pass B: y += coef * w for every column of the block, unconditionally (coef = 0 leaves a state as it is: a branch around
               // the pass makes the compiler copy all state registers where the two paths meet)
-                f32x4 wb[2];
-                wb[0] = wload(0);
+                // (two fused multiply-adds per chunk and column do not cover an LDS round trip: with the row element one chunk ahead, as
+                //  in pass A, the pass waited ~100 cycles per chunk -- 0.8-1.0 of a half-step's 2.3 ms at config 3; KLT_PBD chunks ahead)
+                constexpr int PD = (EPT4 < KLT_PBD) ? EPT4 : KLT_PBD;
+                f32x4 wb[PD + 1];
 #pragma unroll
-                for (int e = 0; e < EPT4; e++) {
+                for (int e = 0; e < PD; e++)
+                    if (KLT_HAS(e)) wb[e] = wload(e);
+#pragma unroll
+                for (int e = 0; e < ((KLT_EXP & 4) ? 0 : EPT4); e++) {
                     if (KLT_HAS(e)) { // wave-uniform
-                        if (e + 1 < EPT4 && KLT_HAS(e + 1)) wb[(e + 1) & 1] = wload(e + 1);
-                        const f32x4 w = wb[e & 1];
+                        if (e + PD < EPT4 && KLT_HAS(e + PD)) wb[(e + PD) % (PD + 1)] = wload(e + PD);
+                        const f32x4 w = wb[e % (PD + 1)];
 #pragma unroll
                         for (int c = 0; c < C; c++) y[c][e] = __builtin_elementwise_fma(f32x4{coef[c], coef[c], coef[c], coef[c]}, w, y[c][e]); // :106, :143
                     }
