@@ -28,7 +28,7 @@ if [[ $WHAT == *pmc* ]]; then
   run() { # tag name counters cfg prec
     (cd /tmp && timeout 900 rocprofv3 --pmc $3 --output-format csv -d $O/pmc_$2 -o p -- python $R/bench.py --config $4 --precision $5 --steps 4 --warmup 1 --cpu-iters 0 --repeats 1 --others 0 > /dev/null 2> $O/$1_pmc_$2.err; echo "pmc $1 $2 exit=$?")
     f=$(find $O/pmc_$2 -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python $R/scripts/pmc_summary.py "$(dirname "$f")" | grep -E "sweep_scd_q|xprod16|kl_tile|kl_reg64|na_gram|colsolve|errors_|xprod_tn|factor16|wh_store" >> $O/$1_pmc_summary.txt
+    [ -n "$f" ] && python $R/scripts/pmc_summary.py "$(dirname "$f")" | grep -E "sweep_scd_q|xprod16|kl_tile|kl_reg64|na_gram|colsolve|errors|xprod_tn|factor16|wh_store" >> $O/$1_pmc_summary.txt
     rm -rf $O/pmc_$2
   }
   for spec in "cfg2 2 f32" "cfg3 3 f32" "cfg5 5 f32" "f64_cfg2 2 f64"; do
