@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restri
 // (op_mode 1: [KP][op_ld] same layout as X, 2: [col][op_ld] kq fastest, 0: none), element type float or double.
 // maxw (optional): max |x| over the factor as the bit pattern of a float (what absmax_f64_kernel computes), for the split-fp16 copy of
 // the NEXT half-step, whose fixed factor this is -- the unpack reads every entry anyway.  Zeroed by the caller.
+// rank_stride: doubles between the payloads of two ranks (KP * cpr, + the Gram partial sums that travel behind the slab: below).
 __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KP, int cpr, int k,
                                                            int ncols, double *__restrict__ X, int ldx, void *__restrict__ op,
-                                                           int op_mode, int op_ld, int op_f64, unsigned *__restrict__ maxw)
+                                                           int op_mode, int op_ld, int op_f64, unsigned *__restrict__ maxw, size_t rank_stride)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t per_rank = (size_t)KP * cpr;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
         col = rr * cpr + (int)(e % cpr);
         live = q < k && col < ncols;
     }
-    const double v = live ? packed[e] : 0.0;
+    const double v = live ? packed[(e / per_rank) * rank_stride + e % per_rank] : 0.0;
     if (maxw) { // (whole wavefronts stay together for the reduction)
         mx = fabsf((float)v);
 #pragma unroll
@@ -182,4 +183,17 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
         if (op_f64) ((double *)op)[(size_t)q * op_ld + col] = v;
         else ((float *)op)[(size_t)q * op_ld + col] = (float)v;
     }
+}
+
+// Multi-GPU, dense SCD: every rank's sweep leaves the Gram partial sums of ITS columns behind (k_sweep_q.h's epilogue, folded into
+// one KP x KP matrix behind its packed slab); after the all-gather the Gram of the whole factor -- the fixed factor of the next
+// half-step -- is their sum in rank order: G[e] = sum_r packed[r * rank_stride + tail_off + e].  Identical on every rank.
+__global__ __launch_bounds__(256) void shard_gram_sum_kernel(const double *__restrict__ packed, int nranks, size_t rank_stride, size_t tail_off,
+                                                             int cnt, double *__restrict__ G)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cnt) return;
+    double s = 0.0;
+    for (int r = 0; r < nranks; r++) s += packed[(size_t)r * rank_stride + tail_off + e];
+    G[e] = s;
 }

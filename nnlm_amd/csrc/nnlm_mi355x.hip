@@ -60,6 +60,8 @@ struct nnlm_handle {
     bool any_missing = false;
     bool dense_cols = true;     // multi-GPU form of the dense square-loss half-step (half_step): column-sharded (true) or all-reduce
     int upk_max_for = -1;       // multi-GPU: the half-step (0: W, 1: H) whose unpack left max|factor| in maxbits[6 + which], or -1
+    int gshard_for = -1;        // multi-GPU: the factor (0: W, 1: H) whose Gram the last unpack summed into Graw from the ranks' partial sums, or -1
+    size_t pack_tail = 0;       // doubles behind the k x cpr slab in the packed payload of the current half-step (KP * KP Gram partial sums, or 0)
     unsigned *fixed_maxw = nullptr; // word holding max|fixed factor| of the half-step in progress (split-fp16 copies)
     double n_non_missing = 0.0, kl_const = 0.0;
 
@@ -588,6 +590,7 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
     h->upk_max_for = -1;
+    h->gshard_for = -1;
     if (k != h->k) {
         free_factors(h);
         h->k = k;
@@ -1303,7 +1306,7 @@ enum { PH_ALL = 0, PH_A = 1, PH_B = 2, PH_C = 3 };
 static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
                            int nslabs, bool speculative, int phase, bool colshard = false);
 
-static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out);
+static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out, size_t tail);
 static int pack_gather_unpack(nnlm_handle *h, int which, int phase);
 
 // Columns of the factor being solved that this rank sweeps (multi-GPU): equal slabs of cpr columns (multiple of 256).
@@ -1326,6 +1329,7 @@ static int ensure_na_lists(nnlm_handle *h, int which, const uint32_t *bits, int 
 static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
                         bool speculative, int phase)
 {
+    h->pack_tail = 0; // (the KL slabs travel alone)
     if (h->sharded && phase == PH_A) return NNLM_OK; // (test hooks: nothing to all-reduce)
     if (h->sharded && phase == PH_C) {
         int rc = pack_gather_unpack(h, which, phase);
@@ -1362,7 +1366,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     a.ldo = a.ldx;
     if (h->sharded) { // this rank's columns only, into the packed slab; the unpack writes masters and operands
         ShardCols sc;
-        int rcp = pack_prepare(h, ncols_all, &sc);
+        int rcp = pack_prepare(h, ncols_all, &sc, 0);
         if (rcp != NNLM_OK) return rcp;
         a.col0 = sc.col0;
         a.ncols = sc.col1;
@@ -1643,7 +1647,11 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // only as its workgroups retired and stretched from 0.03 to 0.5-1.0 ms while slowing the cross product down with it --
     // profiles/r03_f64_cfg2_a_kernel_stats.csv: xprod_tn 0.44 .. 1.6 ms, gram_partial 0.03 .. 0.99 ms.)
     int gslabs = 0;
-    {
+    // (multi-GPU, dense SCD, column form: the unpack of the previous half-step already summed the ranks' Gram partial sums of this
+    //  half-step's fixed factor into Graw -- shard_gram_sum_kernel -- instead of every rank recomputing the whole Gram)
+    const bool gram_cached = colshard && method == 1 && !h->any_missing && !generic_rank(h) && h->gshard_for == ((which == 1) ? 0 : 1);
+    if (!gram_cached) {
+        h->gshard_for = -1;
         ProfScope ps(h, P_GRAM, h->stream);
         const int CE = stage_elems(h, which);
         int c0 = p.stage_begin * CE, c1 = p.stage_end * CE;
@@ -1699,22 +1707,30 @@ static int shard_unpack(nnlm_handle *h, int which)
     unsigned *maxw = h->x16 ? h->maxbits + 6 + which : nullptr; // max|factor| for the next half-step's split copy (no absmax pass there)
     if (maxw) HIPCHK(h, hipMemsetAsync(maxw, 0, sizeof(unsigned), h->stream));
     h->upk_max_for = maxw ? which : -1;
+    const size_t rank_stride = (size_t)h->k * sc.cpr + h->pack_tail;
     if (which == 1)
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols, h->H64,
-                                                                                   h->mpad, nullptr, 0, 0, f64, maxw);
+                                                                                   h->mpad, nullptr, 0, 0, f64, maxw, rank_stride);
     else
         shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols,
                                                                                    h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
-                                                                                   f64 ? 0 : 1, h->npad, f64, maxw);
+                                                                                   f64 ? 0 : 1, h->npad, f64, maxw, rank_stride);
+    if (h->gshard_for == which) h->gshard_for = -1; // (that factor has just been rewritten)
+    if (h->pack_tail) { // the Gram of the factor just gathered = the sum of the ranks' partial sums, in rank order
+        const int cnt = h->KP * h->KP;
+        shard_gram_sum_kernel<<<(cnt + 255) / 256, 256, 0, h->stream>>>(h->pack_all, h->nranks, rank_stride, (size_t)h->k * sc.cpr, cnt, h->Graw);
+        h->gshard_for = which;
+    }
     HIPCHK(h, hipGetLastError());
     return NNLM_OK;
 }
 
 // packed slab [KP][cpr] this rank solves its columns into (zeroed) and the gathered [nranks][KP][cpr]
-static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out)
+// tail: doubles that travel behind the slab's k meaningful rows (at offset k * cpr: the slab's padding rows are not gathered)
+static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out, size_t tail)
 {
     const ShardCols sc = shard_cols(h, ncols);
-    const size_t need = (size_t)h->KP * sc.cpr;
+    const size_t need = (size_t)h->KP * sc.cpr + tail;
     if (h->pack_elems < need * h->nranks) {
         hipFree(h->pack_send);
         hipFree(h->pack_all);
@@ -1734,7 +1750,8 @@ static int pack_gather_unpack(nnlm_handle *h, int which, int phase)
     const int ncols = (which == 1) ? h->m : h->n;
     const ShardCols sc = shard_cols(h, ncols);
     if (h->comm) {
-        ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->k * sc.cpr, ncclDouble, (ncclComm_t)h->comm, h->stream); // rows 0 .. k-1
+        ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->k * sc.cpr + h->pack_tail, ncclDouble, (ncclComm_t)h->comm,
+                                          h->stream); // rows 0 .. k-1 (+ the Gram partial sums behind them)
         if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     } else if (phase == PH_ALL)
         return fail(h, NNLM_ERR_COMM, "virtual rank %d of %d has no communicator: drive it with nnlm_debug_phase()", h->rank, h->nranks);
@@ -1748,6 +1765,8 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                            int nslabs, bool speculative, int phase, bool colshard)
 {
     const int ncols = (which == 1) ? h->m : h->n;
+    // dense SCD in the column form: the Gram partial sums of this rank's columns travel with its slab (shard_gram_sum_kernel)
+    h->pack_tail = (h->sharded && colshard && method == 1 && !h->any_missing && !generic_rank(h)) ? (size_t)h->KP * h->KP : 0;
     if (phase != PH_C) {
         ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
         SweepArgs a;
@@ -1796,7 +1815,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         a.op_f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
         if (h->sharded) { // sweep only this rank's columns into the packed slab; the unpack writes masters and operands
             ShardCols sc;
-            int rcp = pack_prepare(h, ncols, &sc);
+            int rcp = pack_prepare(h, ncols, &sc, h->pack_tail);
             if (rcp != NNLM_OK) return rcp;
             a.col0 = sc.col0;
             a.ncols = sc.col1;
@@ -1805,6 +1824,13 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             a.ocol0 = sc.col0;
             a.op = nullptr;
             a.op_mode = 0;
+            if (h->pack_tail) {
+                if (!h->sg_slabs) {
+                    const int big = h->n > h->m ? h->n : h->m;
+                    HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)((big + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1) * h->KP * h->KP * 8));
+                }
+                a.gram_slabs = h->sg_slabs; // (one slab per workgroup of sweep_scd_q_kernel; folded behind the packed slab below)
+            }
         }
         if (h->any_missing) {
             // per-column Gram over the finite rows of each column (src/update_with_missing.cpp:90), then the solver
@@ -1822,6 +1848,10 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         } else if (a.ncols > a.col0) {
             int rcs = launch_sweep(h, method, a);
             if (rcs != NNLM_OK) return rcs;
+            if (h->sharded && h->pack_tail) {
+                const int nsl = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
+                gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, nsl, h->KP, h->pack_send + (size_t)h->k * a.ldo);
+            }
             if (sg) { // the next half-step finds max and Gram partial sums of this factor
                 h->sg_nslabs = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
                 h->sg_par ^= 1;
@@ -1912,7 +1942,7 @@ extern "C" int nnlm_debug_exchange(nnlm_handle **hs, int P, int which, int stage
     } else {
         const int ncols = (which == 1) ? h0->m : h0->n;
         const ShardCols sc = shard_cols(h0, ncols);
-        const size_t per = (size_t)h0->k * sc.cpr; // (as the ncclAllGather call: the first k rows of the slab)
+        const size_t per = (size_t)h0->k * sc.cpr + h0->pack_tail; // (as the ncclAllGather call: the first k rows of the slab + its tail)
         std::vector<double> all(per * P);
         for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(all.data() + per * r, hs[r]->pack_send, per * 8, hipMemcpyDeviceToHost));
         for (int r = 0; r < P; r++) HIPCHK(hs[r], hipMemcpy(hs[r]->pack_all, all.data(), per * P * 8, hipMemcpyHostToDevice));
@@ -2150,6 +2180,8 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     h->rank = rank;
     h->nranks = nranks;
     h->upk_max_for = -1; // (the cached max|factor| of an unpack belongs to the previous communicator's exchange)
+    h->gshard_for = -1;
+    h->pack_tail = 0;
     h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
     {
         const char *form = getenv("NNLM_SHARD_DENSE"); // "reduce": contraction-sharded + all-reduce; default "cols": column-sharded, all-gather only
