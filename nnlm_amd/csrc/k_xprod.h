@@ -51,6 +51,19 @@ __device__ static inline void wait_vmcnt(int n)
     }
 }
 
+// global_load_lds_dwordx4 written out: scalar base (wave-uniform), one 32-bit per-lane byte offset, LDS base in M0.  The builtin
+// form (glds16) takes a 64-bit per-lane address: 5-6 vector instructions per request to rebuild it (v_lshl_add_u64 x2,
+// v_readfirstlane for M0, moves) -- a third of what a wavefront of the cross-product kernels issues per stage.
+__device__ __forceinline__ unsigned long long xp_uniform64(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void glds16_s(unsigned voff, unsigned long long sbase, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // number of indices u in {wave, wave + 8, ...} below cnt
 __device__ static inline int strided_count(int wave, int cnt) { return (wave < cnt) ? (cnt - wave + XPROD_WAVES - 1) / XPROD_WAVES : 0; }
 

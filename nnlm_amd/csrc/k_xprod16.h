@@ -54,7 +54,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
     constexpr int YI = KP / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int j0 = blockIdx.x * XPROD_TN_BJ;
     int st0 = stage_begin + blockIdx.y * stages_per_split;
@@ -71,31 +71,35 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
     }
 
     // a stage = one 256-byte chunk ([64 hi | 64 lo]) of 128 columns of A and of KP rows of the factor; the sixteen
-    // 16-byte slots of a row are XOR-swizzled with the row index through the global source address (as in k_xprod.h)
-    auto issue = [&](int st, unsigned char *buf) {
-        const size_t c0 = (size_t)((EXP & 4) && st > st0 + 1 ? st0 : st) * 64; // element offset of the chunk (64 words of 4 bytes)
+    // 16-byte slots of a row are XOR-swizzled with the row index through the global source address (as in k_xprod.h).
+    // Piece t = wave + 8 i of an image = rows 4 t + lg: (row & 15) = (4 wave + lg) & 15 for every i, so ONE per-lane byte offset
+    // per image serves all of a wavefront's requests; piece and stage go into the scalar base.
+    const int rw = 4 * wave + lg, sw = l15 ^ (rw & 15);
+    const unsigned voffA = (unsigned)(((size_t)rw * lda + sw * 4) * 4), voffY = (unsigned)(((size_t)rw * ldy + sw * 4) * 4);
+    const unsigned long long baseA = xp_uniform64(A16 + (size_t)j0 * lda), baseY = xp_uniform64(Y16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
+    auto issue = [&](int st, int bi) {
+        const unsigned long long c0b = (unsigned long long)((EXP & 4) && st > st0 + 1 ? st0 : st) * 256ull; // byte offset of the chunk
+        const unsigned dst = lds0 + (unsigned)bi * (unsigned)BUF + (unsigned)wave * 1024u;
 #pragma unroll
-        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(A16 + (size_t)(j0 + row) * lda + c0 + s * 4, buf + t * 1024);
-        }
+        for (int i = 0; i < XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES; i++)
+            glds16_s(voffA, baseA + c0b + (unsigned long long)i * 32ull * (unsigned long long)lda * 4ull, dst + (unsigned)i * 8192u);
 #pragma unroll
-        for (int t = wave; t < YI; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(Y16 + (size_t)row * ldy + c0 + s * 4, buf + XPROD_A_IMG_BYTES + t * 1024);
-        }
+        for (int i = 0; i < (YI + XPROD_WAVES - 1) / XPROD_WAVES; i++)
+            if (wave + XPROD_WAVES * i < YI)
+                glds16_s(voffY, baseY + c0b + (unsigned long long)i * 32ull * (unsigned long long)ldy * 4ull,
+                         dst + (unsigned)XPROD_A_IMG_BYTES + (unsigned)i * 8192u);
     };
     const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
-    if (st0 < st1) issue(st0, smem);
-    if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
+    if (st0 < st1) issue(st0, 0);
+    if (st0 + 1 < st1) issue(st0 + 1, 1);
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
         unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
         wait_vmcnt((st + 1 < st1) ? per_stage : 0);
         __builtin_amdgcn_s_barrier();
-        if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        asm volatile("" ::: "memory");
+        if (st + 2 < st1) issue(st + 2, (st + 2 - st0) % XPROD_NBUF);
         if (EXP & 2) continue;
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks per stage; lane (l15, lg) holds elements 32*c2 + 8*lg .. +7
