@@ -553,6 +553,9 @@ __device__ static inline float kl_wave_total(float v)
     return v;
 }
 #define KLT_THREADS 512
+#ifndef KLT_PBD1
+#define KLT_PBD1 1 // the same in the one-buffer form (160 state registers at 20 pieces)
+#endif
 #ifndef KLT_PBD
 #define KLT_PBD 5 // pass B: row elements requested this many chunks ahead
 #endif
@@ -571,20 +574,35 @@ __device__ static inline float kl_wave_total(float v)
 // dynamic LDS of kl_tile_kernel: two row buffers, coordinates and row sums of the C columns, reduction scratch
 // (a staged row is a whole number of 64 x 16-byte wavefront pieces: which pieces exist is then wave-uniform)
 __host__ __device__ static inline int kl_tile_p4(int p) { return ((p + 3) / 4 + 63) / 64 * 64; }
-__host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0)
+__host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0, int nbuf = 2)
 {
-    return 2 * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * 8 * 4 + (size_t)C * mw_masked * 8;
+    return nbuf * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * 8 * 4 + (size_t)C * mw_masked * 8;
+}
+// s_waitcnt vmcnt(n), n wave-uniform at run time (0 .. 19: the pieces of a row a wavefront may have in flight)
+__device__ static inline void klt_wait_vm(int n)
+{
+    switch (n) {
+#define KLT_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        KLT_W(1) KLT_W(2) KLT_W(3) KLT_W(4) KLT_W(5) KLT_W(6) KLT_W(7) KLT_W(8) KLT_W(9) KLT_W(10) KLT_W(11) KLT_W(12) KLT_W(13) KLT_W(14)
+        KLT_W(15) KLT_W(16) KLT_W(17) KLT_W(18) KLT_W(19)
+#undef KLT_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
-template <int EPT4, int C, int METHOD>
+// ONEBUF (contractions of 20481 .. ~40400: a row is up to 158 KB, one buffer is all the LDS holds): piece e of the NEXT row is
+// requested into its slot right after pass B has read piece e of this row back, and pass A waits for piece e with a counted
+// s_waitcnt -- the scheme of kl_reg64_kernel.  (Two buffers otherwise: the next row is requested during pass A.)
+template <int EPT4, int C, int METHOD, bool ONEBUF = false>
 __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a)
 {
     constexpr int NV = (METHOD == 4) ? 1 : 2; // sums per column and step: {num} or {a, b}
+    constexpr int NROWBUF = ONEBUF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char kl_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: scalar branches)
     const int k = a.k, P4 = kl_tile_p4(a.p); // float4 slots per row, padded to whole wavefront pieces (the arrays are padded further)
     const int rowb = P4 * 16;
-    double *xs = (double *)(kl_smem + 2 * (size_t)rowb); // [C][k]
+    double *xs = (double *)(kl_smem + NROWBUF * (size_t)rowb); // [C][k]
     double *sws = xs + C * k;                            // [C][k]
     float *red = (float *)(sws + C * k);                 // [2][NV * C][8]
     unsigned long long *mks = (unsigned long long *)(red + 2 * 2 * C * 8); // [C][mw] mask words of the block's columns (a.mask only)
@@ -601,7 +619,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     const int voff = lane * 16, L4 = (int)(a.lda >> 2);
     for (int i = L4 + tid; i < P4; i += KLT_THREADS) {
         *(f32x4 *)(kl_smem + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4 *)(kl_smem + (size_t)rowb + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!ONEBUF) *(f32x4 *)(kl_smem + (size_t)rowb + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // piece e of row q -> buffer bufsel.  An LDS-DMA instruction costs its wavefront ~100 issue cycles, so the pieces of the NEXT
     // row are requested one per chunk of pass A (their issue hides behind the other wavefront's arithmetic), not in a burst at
@@ -684,10 +702,11 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         flag_l = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
             const int qn = (q + 1 < k) ? q + 1 : 0; // next row (row 0 again for a sweep that may follow)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's pieces of row q (requested during step q - 1) have landed
-            const unsigned char *rowp = kl_smem + (size_t)bufsel * rowb;
-            const int nbuf = bufsel ^ 1; // free since pass B of step q - 1
+            if (!ONEBUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's pieces of row q (requested during step q - 1) have landed
+            const unsigned char *rowp = kl_smem + (ONEBUF ? 0 : (size_t)bufsel * rowb);
+            const int nbuf = ONEBUF ? 0 : bufsel ^ 1; // free since pass B of step q - 1
             bufsel ^= 1;
+            const int npm1 = (last ? EPT4 : EPT4 - 1) - 1; // ONEBUF: pieces of row q this wavefront requested (in order) - 1
             bool m_l = false;
             if (a.mask) m_l = (mks[lc * a.mw + (q >> 6)] >> (q & 63)) & 1ull; // (LDS copy: a global load here would drain the row prefetch)
             const bool doq_l = run_l && !m_l;
@@ -704,12 +723,16 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             // compiler from hoisting all EPT4 fetches (and their registers) to the top of the unrolled loop
             auto wload = [&](int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * KLT_THREADS + tid) * 16); };
             f32x4 wq[2]; // (two named registers by the parity of e: no copy per chunk)
+            if (ONEBUF) klt_wait_vm(npm1); // piece 0 has landed once at most the npm1 younger ones are outstanding
             wq[0] = wload(0);
 #pragma unroll
             for (int e = 0; e < EPT4; e++) {
                 if (KLT_HAS(e)) { // wave-uniform (compile-time true for all but the last piece)
-                    if (e + 1 < EPT4 && KLT_HAS(e + 1)) wq[(e + 1) & 1] = wload(e + 1);
-                    issue_piece(qn, nbuf, e);
+                    if (e + 1 < EPT4 && KLT_HAS(e + 1)) {
+                        if (ONEBUF) klt_wait_vm(npm1 - (e + 1));
+                        wq[(e + 1) & 1] = wload(e + 1);
+                    }
+                    if (!ONEBUF) issue_piece(qn, nbuf, e);
                     const f32x4 w = wq[e & 1];
 #pragma unroll
                     for (int c = 0; c < ((KLT_EXP & 8) ? 0 : C); c++) {
@@ -790,7 +813,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
               // the pass makes the compiler copy all state registers where the two paths meet)
                 // (two fused multiply-adds per chunk and column do not cover an LDS round trip: with the row element one chunk ahead, as
                 //  in pass A, the pass waited ~100 cycles per chunk -- 0.8-1.0 of a half-step's 2.3 ms at config 3; KLT_PBD chunks ahead)
-                constexpr int PD = (EPT4 < KLT_PBD) ? EPT4 : KLT_PBD;
+                constexpr int PD = ONEBUF ? KLT_PBD1 : ((EPT4 < KLT_PBD) ? EPT4 : KLT_PBD);
                 f32x4 wb[PD + 1];
 #pragma unroll
                 for (int e = 0; e < PD; e++)
@@ -800,6 +823,10 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     if (KLT_HAS(e)) { // wave-uniform
                         if (e + PD < EPT4 && KLT_HAS(e + PD)) wb[(e + PD) % (PD + 1)] = wload(e + PD);
                         const f32x4 w = wb[e % (PD + 1)];
+                        if (ONEBUF) { // slot e has been read back: the next row's piece goes into it
+                            asm volatile("" : : "v"(w) : "memory");
+                            issue_piece(qn, 0, e);
+                        }
 #pragma unroll
                         for (int c = 0; c < C; c++) y[c][e] = __builtin_elementwise_fma(f32x4{coef[c], coef[c], coef[c], coef[c]}, w, y[c][e]); // :106, :143
                     }

@@ -1068,35 +1068,48 @@ static void launch_kl64(int method, const Kl64Args &ka, hipStream_t s)
 
 // F32 mode: kl_tile_kernel (k_kl.h).  EPT4 = float4 chunks of the contraction per thread, C = columns per workgroup
 // (C * EPT4 * 8 state registers per thread).
-template <int EPT4, int C>
+template <int EPT4, int C, bool ONEBUF = false>
 static void launch_kl_tile_m(int method, const KlTileArgs &ta, int nb, size_t lds, hipStream_t s)
 {
     if (method == 3) {
-        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        kl_tile_kernel<EPT4, C, 3><<<nb, KLT_THREADS, lds, s>>>(ta);
+        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 3, ONEBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_tile_kernel<EPT4, C, 3, ONEBUF><<<nb, KLT_THREADS, lds, s>>>(ta);
     } else {
-        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        kl_tile_kernel<EPT4, C, 4><<<nb, KLT_THREADS, lds, s>>>(ta);
+        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 4, ONEBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kl_tile_kernel<EPT4, C, 4, ONEBUF><<<nb, KLT_THREADS, lds, s>>>(ta);
     }
 }
-static int kl_tile_cols(int ept4) { return ept4 <= 2 ? 8 : (ept4 <= 5 ? 4 : 2); }
+// up to 10 pieces per thread: two row buffers, 2 .. 8 columns per block; 11 .. 20 (contractions up to ~40400): one row buffer, one column
+static int kl_tile_cols(int ept4) { return ept4 <= 2 ? 8 : (ept4 <= 5 ? 4 : (ept4 <= 10 ? 2 : 1)); }
+static int kl_tile_nbuf(int ept4) { return ept4 <= 10 ? 2 : 1; }
 static int kl_tile_ept4(int p)
 {
     const int e = (kl_tile_p4(p) + KLT_THREADS - 1) / KLT_THREADS; // float4 pieces per thread: the instantiation is exact
-    return e <= 10 ? e : 0;                                        // 0: contraction too long for the register-resident kernel
+    return e <= 20 ? e : 0;                                        // 0: contraction too long for the register-resident kernel
 }
 static bool kl_tile_fits(int p, int k, int mw_masked)
 {
     const int e = kl_tile_ept4(p);
-    return e > 0 && kl_tile_lds_bytes(p, k, kl_tile_cols(e), mw_masked) <= (size_t)160 * 1024 && 2 * round_up_i(k, 2) * ERRF_TILE * 4 <= 160 * 1024;
+    return e > 0 && kl_tile_lds_bytes(p, k, kl_tile_cols(e), mw_masked, kl_tile_nbuf(e)) <= (size_t)160 * 1024 &&
+           2 * round_up_i(k, 2) * ERRF_TILE * 4 <= 160 * 1024;
 }
 static void launch_kl_tile(int method, const KlTileArgs &ta, hipStream_t s)
 {
     const int e = kl_tile_ept4(ta.p), C = kl_tile_cols(e);
     const int nb = (ta.ncols - ta.colbase + C - 1) / C;
     if (nb <= 0) return;
-    const size_t lds = kl_tile_lds_bytes(ta.p, ta.k, C, ta.mask ? ta.mw : 0);
+    const size_t lds = kl_tile_lds_bytes(ta.p, ta.k, C, ta.mask ? ta.mw : 0, kl_tile_nbuf(e));
     switch (e) {
+    case 11: launch_kl_tile_m<11, 1, true>(method, ta, nb, lds, s); break;
+    case 12: launch_kl_tile_m<12, 1, true>(method, ta, nb, lds, s); break;
+    case 13: launch_kl_tile_m<13, 1, true>(method, ta, nb, lds, s); break;
+    case 14: launch_kl_tile_m<14, 1, true>(method, ta, nb, lds, s); break;
+    case 15: launch_kl_tile_m<15, 1, true>(method, ta, nb, lds, s); break;
+    case 16: launch_kl_tile_m<16, 1, true>(method, ta, nb, lds, s); break;
+    case 17: launch_kl_tile_m<17, 1, true>(method, ta, nb, lds, s); break;
+    case 18: launch_kl_tile_m<18, 1, true>(method, ta, nb, lds, s); break;
+    case 19: launch_kl_tile_m<19, 1, true>(method, ta, nb, lds, s); break;
+    case 20: launch_kl_tile_m<20, 1, true>(method, ta, nb, lds, s); break;
     case 1: launch_kl_tile_m<1, 8>(method, ta, nb, lds, s); break;
     case 2: launch_kl_tile_m<2, 8>(method, ta, nb, lds, s); break;
     case 3: launch_kl_tile_m<3, 4>(method, ta, nb, lds, s); break;

@@ -253,3 +253,28 @@ def test_config5_strict_f64_full_size_one_iteration():
     assert ew < 1e-9 and eh < 1e-9, (ew, eh)
     assert np.array_equal(r["average_epoch"], o["average_epoch"])
     assert d_mse < 1e-9 and d_tgt < 1e-9
+
+
+@pytest.mark.parametrize("pname,prec,tol", [("f32", _lib.PREC_F32, 1e-4), ("f64", _lib.PREC_F64, 1e-10)])
+def test_config2_lee_ls_full_size_one_iteration(pname, prec, tol):
+    """SURVEY 8a row a6 (lee_ls_update, src/base_algorithms.cpp:40-68) at the benchmark's size: one outer iteration of Lee's
+    multiplicative updates under square loss (5 inner sweeps) with regularisation, both arithmetic modes, against the oracle."""
+    A, W0, H0 = inputs()
+    reg = [0.01, 0.005, 0.01]
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(K, W0, H0)
+        h.iterate(1, reg, reg, 5, 1e-9, 2)
+        W1, H1 = h.get_factors()
+        sweeps = h.take_sweeps()
+        mse, kl, pen = h.errors()
+    o = ref.c_nnmf(A, K, W0, H0, None, None, reg, reg, 1, -1.0, 0, 0, False, 5, 1e-9, 2, 1)
+    ew, eh = relF(W1, o["W"]), relF(H1, o["H"])
+    d_mse = abs(mse - o["mse_error"][-1]) / o["mse_error"][-1]
+    report(f"config2_lee_ls_{pname}_1_iteration", relF_W=ew, relF_H=eh, rel_mse=d_mse, epoch_gpu=sweeps / (N + M), epoch_oracle=float(o["average_epoch"][-1]))
+    assert ew < tol and eh < tol, (ew, eh)
+    assert d_mse < (1e-5 if pname == "f32" else 1e-10)
+    if pname == "f64":
+        assert sweeps / (N + M) == float(o["average_epoch"][-1])  # sweep counts exact in the reference's arithmetic
+    assert np.all(W1 >= 0) and np.all(H1 >= 0)
+
