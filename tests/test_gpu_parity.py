@@ -595,11 +595,13 @@ def test_nnlm_with_more_than_64_predictors(monkeypatch):
 
 @pytest.mark.parametrize("pname,prec,tol", [("f64", _lib.PREC_F64, 1e-10), ("f32", _lib.PREC_F32, 1e-4)])
 @pytest.mark.parametrize("method", [3, 4])
-def test_kl_contraction_longer_than_32768(pname, prec, tol, method):
-    """nnmf(loss = 'mkl') on a 40000 x 9 matrix: the H half-step contracts over 40000 rows (the reference streams any
-    length, src/base_algorithms.cpp:71-151), the W half-step solves 40000 columns."""
+@pytest.mark.parametrize("n", [23000, 40000, 41500])
+def test_kl_contraction_longer_than_32768(pname, prec, tol, method, n):
+    """nnmf(loss = 'mkl') on an n x 9 matrix: the H half-step contracts over n rows (the reference streams any length,
+    src/base_algorithms.cpp:71-151), the W half-step solves n columns.  F32 mode: 23000 and 40000 take the one-row-buffer form of
+    kl_tile_kernel (12 / 20 pieces per thread), 41500 kl_stream_kernel; strict mode: kl_stream_kernel beyond 20480."""
     rng = np.random.default_rng(method)
-    n, m, k = 40000, 9, 3
+    m, k = 9, 3
     A = rng.random((n, m))
     A[rng.random((n, m)) < 0.02] = np.nan
     W0, H0 = rng.random((n, k)), rng.random((k, m))
