@@ -1402,16 +1402,24 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         const int k2 = round_up_i(h->k, 2);
         const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
         hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        // (multi-GPU: only the column tiles of this rank's shard -- its first column is a multiple of 256)
+        const int ct0 = a.col0 / ERRF_TILE, ct1 = (a.ncols + ERRF_TILE - 1) / ERRF_TILE;
+        const int ny = ct1 > ct0 ? ct1 - ct0 : 0;
+        const size_t cofs = (size_t)ct0 * ERRF_TILE;
         if (which == 1) {
-            const int nx = h->npad / ERRF_TILE, ny = h->mpad / ERRF_TILE;
-            wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq, h->mpad, k2, h->What, h->npad, nx);
+            const int nx = h->npad / ERRF_TILE;
+            if (ny > 0)
+                wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq + cofs, h->mpad, k2,
+                                                                                     h->What + cofs * h->npad, h->npad, nx);
             ta.Adata = (const float *)h->A;
             ta.Yf = (const float *)h->Wop;
         } else { // roles swapped: What^T [row of A][column of A], next to the transposed fp32 copy of A
             int rc = ensure_AT(h);
             if (rc != NNLM_OK) return rc;
-            const int nx = h->mpad / ERRF_TILE, ny = h->npad / ERRF_TILE;
-            wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop, h->npad, k2, h->What, h->mpad, nx);
+            const int nx = h->mpad / ERRF_TILE;
+            if (ny > 0)
+                wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop + cofs, h->npad, k2,
+                                                                                     h->What + cofs * h->mpad, h->mpad, nx);
             ta.Adata = (const float *)h->AT;
             ta.Yf = h->Hkq;
         }
@@ -1437,8 +1445,10 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
             int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, ncols_all);
             if (rc != NNLM_OK) return rc;
             factor_rows_kernel<<<(a.p + 255) / 256, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->KP, h->Yrow);
-            kl_sumw_cols_kernel<<<(ncols_all + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
-                                                                           h->klsw, h->klsw_cols, h->KP, ncols_all);
+            if (a.ncols > a.col0) // (this rank's columns only)
+                kl_sumw_cols_kernel<<<(a.ncols - a.col0 + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which] + a.col0, h->na_meta[which] + a.col0, h->na_idx[which],
+                                                                                      h->Yrow, h->KP, h->k, h->klsw, h->klsw_cols + (size_t)a.col0 * h->KP, h->KP,
+                                                                                      a.ncols - a.col0);
             ta.sumw_cols = h->klsw_cols;
         }
         ta.r0 = reg[0];
@@ -1459,15 +1469,23 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         if (!h->What64) HIPCHK(h, hipMalloc(&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096));
         if (!h->klsw) HIPCHK(h, hipMalloc(&h->klsw, (size_t)h->KP * 8));
         const int k4 = round_up_i(h->k, 4);
+        // (multi-GPU: only the column tiles of this rank's shard -- its first column is a multiple of 256)
+        const int ct0 = a.col0 / 64, ct1 = (a.ncols + 63) / 64;
+        const int ny = ct1 > ct0 ? ct1 - ct0 : 0;
+        const size_t cofs = (size_t)ct0 * 64;
         if (which == 1) { // What64[j][i], the layout of A
-            dim3 grid(h->npad / 64, h->mpad / 64);
-            wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->W64, h->npad, h->H64, h->mpad, k4, h->What64, (size_t)h->npad, h->n, h->m);
+            dim3 grid(h->npad / 64, ny > 0 ? ny : 1);
+            if (ny > 0)
+                wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->W64, h->npad, h->H64 + cofs, h->mpad, k4, h->What64 + cofs * h->npad, (size_t)h->npad,
+                                                               h->n, h->m - (int)cofs);
             ka.Adata = (const double *)h->A;
         } else { // roles swapped: What64^T [row of A][column of A], next to the transposed copy of A
             int rc = ensure_AT(h);
             if (rc != NNLM_OK) return rc;
-            dim3 grid(h->mpad / 64, h->npad / 64);
-            wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->H64, h->mpad, h->W64, h->npad, k4, h->What64, (size_t)h->mpad, h->m, h->n);
+            dim3 grid(h->mpad / 64, ny > 0 ? ny : 1);
+            if (ny > 0)
+                wh_store64_kernel<<<grid, 256, 0, h->stream>>>(h->H64, h->mpad, h->W64 + cofs, h->npad, k4, h->What64 + cofs * h->mpad, (size_t)h->mpad,
+                                                               h->m, h->n - (int)cofs);
             ka.Adata = (const double *)h->AT;
         }
         ka.lda = (size_t)ld_con;
@@ -1493,8 +1511,10 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
             int rc = ensure_na_lists(h, which, a.bits, a.words, a.p, ncols_all);
             if (rc != NNLM_OK) return rc;
             factor_rows_kernel<<<(a.p + 255) / 256, 256, 0, h->stream>>>(a.Y, a.ldy, a.p, h->KP, h->Yrow);
-            kl_sumw_cols_kernel<<<(ncols_all + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], h->Yrow, h->KP, h->k,
-                                                                           h->klsw, h->klsw_cols, h->KP, ncols_all);
+            if (a.ncols > a.col0) // (this rank's columns only)
+                kl_sumw_cols_kernel<<<(a.ncols - a.col0 + 3) / 4, 256, 0, h->stream>>>(h->na_ptr[which] + a.col0, h->na_meta[which] + a.col0, h->na_idx[which],
+                                                                                      h->Yrow, h->KP, h->k, h->klsw, h->klsw_cols + (size_t)a.col0 * h->KP, h->KP,
+                                                                                      a.ncols - a.col0);
             ka.sumw_cols = h->klsw_cols;
         }
         ka.r0 = reg[0];
