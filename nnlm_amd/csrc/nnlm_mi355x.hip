@@ -1683,7 +1683,21 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // (multi-GPU, dense SCD, column form: the unpack of the previous half-step already summed the ranks' Gram partial sums of this
     //  half-step's fixed factor into Graw -- shard_gram_sum_kernel -- instead of every rank recomputing the whole Gram)
     const bool gram_cached = colshard && method == 1 && !h->any_missing && !generic_rank(h) && h->gshard_for == ((which == 1) ? 0 : 1);
-    if (!gram_cached) {
+    // (one GPU, strict mode, dense SCD: the sweep that solved the fixed factor left the Gram partial sums of its workgroups behind, as
+    //  in the split-fp16 flow above -- one fold instead of gram_partial + gram_reduce over the whole factor)
+    const bool sg_strict = !h->sharded && !h->x16 && h->prec == NNLM_PREC_F64 && method == 1 && !h->any_missing && !generic_rank(h);
+    if (sg_strict) {
+        if (!h->sg_slabs) {
+            const int big = h->n > h->m ? h->n : h->m;
+            HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)((big + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1) * h->KP * h->KP * 8));
+        }
+        h->sg_request = true; // this half-step's sweep leaves its slabs for the next one
+    }
+    if (sg_strict && sg_which == ((which == 1) ? 0 : 1)) {
+        ProfScope ps(h, P_GRAM, h->stream);
+        gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+        h->gshard_for = -1;
+    } else if (!gram_cached) {
         h->gshard_for = -1;
         ProfScope ps(h, P_GRAM, h->stream);
         const int CE = stage_elems(h, which);
@@ -1819,7 +1833,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
         const bool sg = h->sg_request; // (only on the dense one-GPU split-fp16 path, where k_sweep_q.h runs)
         h->sg_request = false;
         if (sg) {
-            a.maxbits = h->maxbits + 4 + (h->sg_par ^ 1);
+            a.maxbits = h->x16 ? h->maxbits + 4 + (h->sg_par ^ 1) : nullptr; // (max|x| is the split copy's scale: fp32-operand mode only)
             a.gram_slabs = h->sg_slabs;
         }
         if (which == 1) {

@@ -413,21 +413,19 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(monkeypatch, pname,
         # which eight half-steps of coordinate descent amplify to ~1e-7 (scripts/gpu_sg_ab.py); the mode's parity bound is 1e-4
         assert relF(a[0], b[0]) < 1e-5 and relF(a[1], b[1]) < 1e-5 and abs(a[2] - b[2]) <= 2
         assert np.isclose(a[3], b[3], rtol=1e-6) and np.isclose(a[4], b[4], rtol=1e-6) and np.allclose(a[5], b[5], rtol=1e-6)
-    elif form == "cols":
-        # strict mode, column form: since round 3 the Gram of a factor solved by SCD is the sum of the ranks' partial sums (the sweep
-        # kernel's per-workgroup slabs, folded, travelling behind the packed slab) instead of gram_partial_kernel's 256-column
-        # slabs -- the same products in another order of addition (1e-15 in G)
+    else:
+        # strict mode: since round 3 the Gram of a factor solved by SCD comes from the sweep kernel's per-workgroup partial sums on
+        # the plain path (64-column slabs, folded) and in the column form (the ranks' folded sums travel behind the packed slabs),
+        # from gram_partial_kernel's 256-column slabs in the reduce form -- the same products in another order of addition
+        # (1e-15 in G); sweep counts stay equal
         assert relF(a[0], b[0]) < 1e-11 and relF(a[1], b[1]) < 1e-11 and a[2] == b[2]
         assert np.isclose(a[3], b[3], rtol=1e-11) and np.isclose(a[4], b[4], rtol=1e-11) and np.allclose(a[5], b[5], rtol=1e-11)
-    else:
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
-        assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
     for key in ("mse_error", "mkl_error", "target_error", "average_epoch"):
         if pname == "f32" and key != "average_epoch":
             # the plain F32 path evaluates the error sums inside the speculative cross product (xprod16_err_kernel, A rebuilt
             # from its split-fp16 copy), the sharded path with the separate kernel on the fp32 copy: same sums, other rounding
             assert np.allclose(a[6][key], b[6][key], rtol=1e-6, atol=0), key
-        elif form == "cols" and key != "average_epoch":
+        elif key != "average_epoch":
             assert np.allclose(a[6][key], b[6][key], rtol=1e-11, atol=0), key
         else:
             assert np.array_equal(a[6][key], b[6][key]), key
