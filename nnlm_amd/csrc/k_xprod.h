@@ -107,7 +107,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     constexpr int YI = (16 * NKQ + KT + 3) / 4;      // 4-row pieces of the factor image that are actually used
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int j0 = blockIdx.x * XPROD_TN_BJ;
     int st0 = stage_begin + blockIdx.y * stages_per_split;
@@ -130,22 +130,25 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         tacc64[u] = 0.0;
     }
 
+    // Piece t = wave + 8 i of an image = rows 4 t + lg: (row & 15) = (4 wave + lg) & 15 for every i, so ONE per-lane byte offset per
+    // image serves all of a wavefront's requests; piece and stage go into the scalar base (glds16_s).
+    const int rw = 4 * wave + lg, sw = l15 ^ (rw & 15);
+    const unsigned voffA = (unsigned)(((size_t)rw * lda + sw * EPV) * sizeof(T)), voffY = (unsigned)(((size_t)rw * ldy + sw * EPV) * sizeof(T));
+    const unsigned long long baseA = xp_uniform64(A + (size_t)j0 * lda), baseY = xp_uniform64(Yop);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     auto issue = [&](int st, unsigned char *buf) {
-        const size_t i0 = (size_t)(((EXP & 5) == 5 && st > st0 + 1) ? st0 : st) * CE;
+        const unsigned long long bA = (unsigned long long)(((EXP & 4) && st > st0 + 1) ? st0 : st) * XPROD_ROWB;        // EXP: re-read a cached stage
+        const unsigned long long bY = (unsigned long long)(((EXP & 5) == 5 && st > st0 + 1) ? st0 : st) * XPROD_ROWB;
+        const unsigned dst = lds0 + (unsigned)(buf - smem) + (unsigned)wave * 1024u;
 #pragma unroll
-        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            const size_t ia = (size_t)(((EXP & 4) && st > st0 + 1) ? st0 : st) * CE; // EXP: re-read a cached stage
-            glds16(A + (size_t)(j0 + row) * lda + ((EXP & 4) ? ia : i0) + s * EPV, buf + t * 1024);
-        }
+        for (int i = 0; i < XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES; i++)
+            glds16_s(voffA, baseA + bA + (unsigned long long)i * 32ull * (unsigned long long)lda * sizeof(T), dst + (unsigned)i * 8192u);
         if ((EXP & 1) && st > st0 + 1) return;
 #pragma unroll
-        for (int t = wave; t < YI; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(Yop + (size_t)row * ldy + i0 + s * EPV, buf + XPROD_A_IMG_BYTES + t * 1024);
-        }
+        for (int i = 0; i < (YI + XPROD_WAVES - 1) / XPROD_WAVES; i++)
+            if (wave + XPROD_WAVES * i < YI)
+                glds16_s(voffY, baseY + bY + (unsigned long long)i * 32ull * (unsigned long long)ldy * sizeof(T),
+                         dst + (unsigned)XPROD_A_IMG_BYTES + (unsigned)i * 8192u);
     };
 
     // loads THIS wavefront issues per stage (A image: 32 instructions over 8 waves; factor image: KP/4 instructions)
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
         if constexpr ((EXP & 16) == 0) {
             wait_vmcnt((st + 1 < st1) ? per_stage : 0);
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
         }
         if (EXP & 2) continue;
