@@ -17,8 +17,9 @@
 // (The series coefficients live in constant memory, NOT as literals: gfx950's VOP3 encoding has no 64-bit literal operand, so each
 // literal costs a VGPR pair -- 30 registers of a kernel that needs them for occupancy; loaded from a non-const __constant__ array
 // they arrive by s_load and stay in SGPR pairs, one scalar source per fma.)
-static __constant__ double NNLM_LOGC[12] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0,
-                                            1.0 / 5.0,  1.0 / 3.0,  1.9082149292705877e-10, 0.693147180369123816490};
+static __constant__ double NNLM_LOGC[19] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0,
+                                            1.0 / 5.0,  1.0 / 3.0,  1.9082149292705877e-10, 0.693147180369123816490,
+                                            1.0 / 7.0, -1.0 / 6.0, 1.0 / 5.0, -1.0 / 4.0, 1.0 / 3.0, -0.5, 0.69314718055994530942}; // [12..18]: nnlm_log_tab
 __device__ static inline double nnlm_log_pos(double x)
 {
     double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
@@ -40,6 +41,36 @@ __device__ static inline double nnlm_log_pos(double x)
     const double ed = (double)e;
     const double t = __builtin_fma(2.0 * sq * z, p, ed * NNLM_LOGC[10]);
     return __builtin_fma(ed, NNLM_LOGC[11], 2.0 * sq + t);
+}
+
+// ln x for a positive, finite, NORMAL double from a 64-entry table: x = m 2^e, m in [1, 2), bin i = the top six mantissa bits,
+// c_i = 1 + (i + 1/2) / 64, tab[i] = {r_i = fl(1 / c_i), -ln r_i};  t = m r_i - 1 (one fma, exact to rounding, |t| < 2^-7),
+// ln m = -ln r_i + log1p(t) with seven terms of the series (t^8 / 8 < 2e-18).  16 vector instructions + one 16-byte LDS read
+// against 34 for nnlm_log_pos (no quotient, three series terms less).  ABSOLUTE error ~2e-16 (the table value and e ln 2 are single
+// doubles): what a sum of O(1) terms needs -- not the relative accuracy of nnlm_log_pos near x = 1.
+__device__ static inline void nnlm_log_tab_fill(f64x2 *tab, int tid)
+{
+    if (tid < 64) {
+        const double r = 1.0 / (1.0 + (tid + 0.5) * (1.0 / 64.0));
+        tab[tid] = f64x2{r, -nnlm_log_pos(r)};
+    }
+}
+__device__ static inline double nnlm_log_tab(double x, const f64x2 *tab)
+{
+    const int2 xb = __builtin_bit_cast(int2, x);
+    const int e = (int)(((unsigned)xb.y >> 20) & 0x7ffu) - 1023;
+    const int i = (int)(((unsigned)xb.y >> 14) & 63u);
+    const double m = __builtin_bit_cast(double, int2{xb.x, (int)(((unsigned)xb.y & 0x000fffffu) | 0x3ff00000u)});
+    const f64x2 rl = tab[i];
+    const double t = __builtin_fma(m, rl[0], -1.0);
+    double p = NNLM_LOGC[12];
+    p = __builtin_fma(p, t, NNLM_LOGC[13]);
+    p = __builtin_fma(p, t, NNLM_LOGC[14]);
+    p = __builtin_fma(p, t, NNLM_LOGC[15]);
+    p = __builtin_fma(p, t, NNLM_LOGC[16]);
+    p = __builtin_fma(p, t, NNLM_LOGC[17]);
+    const double l1p = __builtin_fma(t * t, p, t); // t - t^2/2 + t^3/3 - ... + t^7/7
+    return __builtin_fma((double)e, NNLM_LOGC[18], l1p + rl[1]);
 }
 
 // partial: [gridDim.y*gridDim.x][2] = {sum (a-ahat)^2, sum -(a+eps)log(ahat+eps)+ahat} over valid entries
@@ -156,7 +187,7 @@ __host__ __device__ static inline int errors64_lds_bytes(int k4) { return 3 * k4
 
 template <bool MASKED>
 __device__ __forceinline__ void errors64_sums(const f64x4 (&acc)[2][2], const double (&av)[2][2][4], const uint32_t (&mw)[2][4], int ivalid,
-                                              int jvalid, int l15, int lg, double &s2, double &skl)
+                                              int jvalid, int l15, int lg, double &s2, double &skl, const f64x2 *ltab)
 {
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -166,7 +197,7 @@ __device__ __forceinline__ void errors64_sums(const f64x4 (&acc)[2][2], const do
             for (int r = 0; r < 4; r++) {
                 const double ah = acc[a][b][r], aa = av[a][b][r];
                 const double d = aa - ah;
-                const double lg_ = nnlm_log_pos(ah + NNLM_TINY);
+                const double lg_ = nnlm_log_tab(ah + NNLM_TINY, ltab);
                 const double term = __builtin_fma(-(aa + NNLM_TINY), lg_, ah);
                 if constexpr (MASKED) {
                     const bool valid = (16 * a + l15 < ivalid) && (16 * b + lg + 4 * r < jvalid) && !((mw[b][r] >> (16 * a + l15)) & 1u);
@@ -235,6 +266,8 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
                     av[a][b][r] = (ERR64_EXP & 4) ? 0.5 : A[(size_t)(jt * ERR_TILE + jb + 16 * b + lg + 4 * r) * lda + i0 + ib + 16 * a + l15];
     };
 
+    __shared__ f64x2 ltab[64]; // nnlm_log_tab
+    nnlm_log_tab_fill(ltab, threadIdx.x);
     double s2 = 0.0, skl = 0.0;
     double av0[2][2][4], av1[2][2][4];
     uint32_t mw0[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, mw1[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -321,8 +354,8 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         tile_a(jn, avn, mwn);
         const bool masked = HAS_MISS || iedge || ((jt + 1) * ERR_TILE > m); // block uniform
         if (ERR64_EXP & 1) s2 += acc[0][0][0] + acc[1][1][3] + acc[0][1][1] + acc[1][0][2] + av[0][0][0] + av[1][1][3];
-        else if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl);
-        else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl);
+        else if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl, ltab);
+        else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl, ltab);
         slice_store(Hs + (1 - buf) * slice_bytes, hr);
     };
     int jt = jt_begin;
