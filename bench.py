@@ -398,7 +398,7 @@ def main():
     if args.others and world == 1 and not force_comm and args.config == 2 and args.precision == "f32" and args.protocol == "default":
         h.close()
         others = {}
-        for key, cid, pr, st, wu in (("config2_strict_f64", 2, "f64", 6, 2), ("config3_kl_lee_f32", 3, "f32", 4, 1), ("config5_na_reg_f32", 5, "f32", 6, 2)):
+        for key, cid, pr, st, wu in (("config2_strict_f64", 2, "f64", 16, 3), ("config3_kl_lee_f32", 3, "f32", 8, 2), ("config5_na_reg_f32", 5, "f32", 12, 2)):
             try:
                 others[key] = other_config(cid, pr, n, m, k, local_rank, st, wu)
             except Exception as e:  # (never lose the headline over a secondary measurement)

@@ -197,16 +197,21 @@ __device__ __forceinline__ void errors64_sums(const f64x4 (&acc)[2][2], const do
             for (int r = 0; r < 4; r++) {
                 const double ah = acc[a][b][r], aa = av[a][b][r];
                 const double d = aa - ah;
-                const double lg_ = nnlm_log_tab(ah + NNLM_TINY, ltab);
+                // (the masked form keeps the table-free logarithm: with the table reads in flight next to the selects it spilled ~900 bytes)
+                const double lg_ = MASKED ? nnlm_log_pos(ah + NNLM_TINY) : nnlm_log_tab(ah + NNLM_TINY, ltab);
                 const double term = __builtin_fma(-(aa + NNLM_TINY), lg_, ah);
                 if constexpr (MASKED) {
-                    const bool valid = (16 * a + l15 < ivalid) && (16 * b + lg + 4 * r < jvalid) && !((mw[b][r] >> (16 * a + l15)) & 1u);
+                    // (lane values against scalars, constant shifts: per-entry lane constants -- lg | 4 r, 1 << (16 a + l15) -- were hoisted
+                    //  out of the tile loop and spilled)
+                    const bool valid = (l15 < ivalid - 16 * a) && (lg < jvalid - (16 * b + 4 * r)) && !(((mw[b][r] >> l15) >> (16 * a)) & 1u);
                     s2 += valid ? d * d : 0.0;
                     skl += valid ? term : 0.0;
                 } else {
                     s2 = __builtin_fma(d, d, s2);
                     skl += term;
                 }
+                // (four entries at a time: with all sixteen table reads hoisted the masked form spilled 928 bytes)
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);
             }
 }
 
@@ -251,6 +256,9 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         }
     };
     auto tile_a = [&](int jt, double (&av)[2][2][4], uint32_t (&mw)[2][4]) {
+        // (addresses rebuilt from an opaque copy of the tile index: as induction variables of the tile loop the 24 of them were kept in
+        //  registers -- 48 VGPRs -- and spilled)
+        asm volatile("" : "+s"(jt));
         if constexpr (HAS_MISS) {
 #pragma unroll
             for (int b = 0; b < 2; b++)
@@ -351,19 +359,30 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (redundant last reads)
 #undef E64_READ
 #undef E64_MMA
-        tile_a(jn, avn, mwn);
+        if constexpr (!HAS_MISS) tile_a(jn, avn, mwn); // (with missing entries: ONE register set, requested behind the sums -- see below)
         const bool masked = HAS_MISS || iedge || ((jt + 1) * ERR_TILE > m); // block uniform
         if (ERR64_EXP & 1) s2 += acc[0][0][0] + acc[1][1][3] + acc[0][1][1] + acc[1][0][2] + av[0][0][0] + av[1][1][3];
         else if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl, ltab);
         else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl, ltab);
+        // (the masked sums + the mask words + two sets of A spilled 136 .. 928 bytes: with missing entries the next tile is requested
+        //  into the SAME set once this tile's sums are done; the next matrix phase covers most of its latency)
+        if constexpr (HAS_MISS) tile_a(jn, avn, mwn);
         slice_store(Hs + (1 - buf) * slice_bytes, hr);
     };
     int jt = jt_begin;
     for (; jt + 1 < jt_end; jt += 2) { // (pairs: the two register sets of A keep their names, no copies)
-        tile(jt, 0, av0, mw0, av1, mw1);
-        tile(jt + 1, 1, av1, mw1, av0, mw0);
+        if constexpr (HAS_MISS) {
+            tile(jt, 0, av0, mw0, av0, mw0);
+            tile(jt + 1, 1, av0, mw0, av0, mw0);
+        } else {
+            tile(jt, 0, av0, mw0, av1, mw1);
+            tile(jt + 1, 1, av1, mw1, av0, mw0);
+        }
     }
-    if (jt < jt_end) tile(jt, 0, av0, mw0, av1, mw1);
+    if (jt < jt_end) {
+        if constexpr (HAS_MISS) tile(jt, 0, av0, mw0, av0, mw0);
+        else tile(jt, 0, av0, mw0, av1, mw1);
+    }
 
     __shared__ double red64[2][4];
     s2 = wave_sum(s2);
