@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
     constexpr int KP = 16 * NKQ;          // row stride of Gfull / Gcols
     constexpr int NP = NKQ * (NKQ + 1) / 2;
     constexpr int STAGE = 8 * 1024;        // bytes: 2 planes x 4 coordinate tiles x [32][16] halves (the split copy always has 64 coordinates)
-    __shared__ __attribute__((aligned(16))) unsigned char stage_all[4][2][STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char stage_all[4][2][STAGE];
     __shared__ int ibuf_all[4][2][64];
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
     const int col = col0 + blockIdx.x * 4 + wave;
@@ -502,25 +502,29 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
     const unsigned long long ybase = sbase(Y16rows), ibase = sbase(idx + base);
     const unsigned lds_stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)stage);
     const unsigned lds_ibuf = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) int *)ibuf);
-    const int r2 = lane >> 1; // row of the step this lane gathers
-    auto issue_idx = [&](int g) { // entries 32 g + lane / 2 of the list (the list array carries 64 words of slack) -> ring slot g & 1
-        const unsigned voff = (unsigned)(32 * g + r2) * 4u;
+    // gather mapping: instruction j of a step fetches rows 4 j .. 4 j + 3 WHOLE (lane l: row 4 j + l / 16, one 16-byte chunk of its
+    // 256 bytes), so the 64 lanes touch 8 cache lines instead of 32 (two rows' 32-byte pieces per quad made the L1's tag stage the bound).
+    // The stage buffer is row-major [32 rows][256 B]; the DMA puts lane l's 16 bytes at slot l & 15 of its row, so the swizzle that
+    // keeps ds_read_b64_tr_b16 conflict free is applied on the GLOBAL side: slot s of row r holds chunk (((s >> 1) ^ f(r)) << 1) | (s & 1),
+    // f(r) = (r & 3) | ((r >> 1) & 4) -- the eight rows one half-wavefront's transpose read touches have eight different f.
+    const int r4 = lane >> 4;
+    const unsigned goff0 = (unsigned)((((lane >> 1) & 7) ^ r4) << 5) | (unsigned)((lane & 1) << 4); // rows with bit 3 clear (j & 2 == 0)
+    auto issue_idx = [&](int g) { // entries 32 g + (lane & 31) of the list (the list array carries 64 words of slack) -> ring slot g & 1
+        const unsigned voff = (unsigned)(32 * g + (lane & 31)) * 4u;
         const unsigned dst = lds_ibuf + (unsigned)(g & 1) * 256u;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(ibase), "s"(dst) : "memory");
     };
-    auto issue_rows = [&](int g) { // the eight subtiles of step g into stage buffer g & 1
-        int row = ibuf[(g & 1) * 64 + lane];
-        if (32 * g + r2 >= ulen) row = zero_row;
-        const unsigned voff = (unsigned)row * 256u + (unsigned)(lane & 1) * 16u;
+    auto issue_rows = [&](int g) { // the 32 rows of step g into stage buffer g & 1, four rows per instruction
+        const int rem = ulen - 32 * g - r4; // rows 4 j + r4 >= ulen - 32 g read the zero row
+        int rows[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) rows[j] = ibuf[(g & 1) * 64 + 4 * j + r4];
         const unsigned dst = lds_stage + (unsigned)(g & 1) * (unsigned)STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { // subtile j = plane (j >> 2), coordinate tile (j & 3): bytes plane * 128 + tile * 32 of the row
-            // (the instruction offset is added to the global address AND to the LDS address: M0 is set back by it)
-            const unsigned off = (unsigned)((j >> 2) * 128 + (j & 3) * 32);
-            if ((j & 3) < NKQ)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(ybase),
-                             "s"(dst + (unsigned)j * 1024u - off), "n"((j >> 2) * 128 + (j & 3) * 32)
-                             : "memory");
+        for (int j = 0; j < 8; j++) {
+            const int row = (4 * j >= rem) ? zero_row : rows[j];
+            const unsigned voff = (unsigned)row * 256u + (goff0 ^ ((j & 2) ? 128u : 0u));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ybase), "s"(dst + (unsigned)j * 1024u) : "memory");
         }
     };
     if (nst > 0) {
@@ -529,8 +533,9 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue_rows(0);
         // operand (plane pl, tile t) of the lane: halves k = 8 lg .. 8 lg + 7 of coordinate 16 t + l15: two transpose reads of
-        // [4 rows][16 halves] blocks, lane (4 j + i) of a 16-lane group addressing row j, halves 4 i .. 4 i + 3
-        const unsigned tr_lane = (unsigned)(8 * lg + (l15 >> 2)) * 32u + (unsigned)(l15 & 3) * 8u;
+        // [4 rows][16 halves] blocks, lane (4 j + i) of a 16-lane group addressing row 8 lg + j (+ 4), halves 4 i .. 4 i + 3 of chunk
+        // pair m = 4 pl + t, which sits at pair slot m ^ f(row): bits 5..7 of the lane's base hold f, so the address is base ^ (m << 5)
+        const unsigned tr_lane = (unsigned)(8 * lg + (l15 >> 2)) * 256u + (unsigned)(((l15 >> 2) | ((lg & 1) << 2)) << 5) + (unsigned)(l15 & 3) * 8u;
         int since = 0;
         for (int g = 0; g < nst; g++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // rows of step g and indices of step g + 1 have landed
@@ -541,10 +546,11 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 #pragma unroll
             for (int t = 0; t < NKQ; t++) {
                 gh4 a0, a1, b0, b1;
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a0) : "v"(sb), "n"(t * 1024));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a1) : "v"(sb), "n"(t * 1024 + 128));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b0) : "v"(sb), "n"(4096 + t * 1024));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b1) : "v"(sb), "n"(4096 + t * 1024 + 128));
+                const unsigned sh = sb ^ (unsigned)(t << 5), sl = sb ^ (unsigned)((4 + t) << 5);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0) : "v"(sh));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(a1) : "v"(sh));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(sl));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b1) : "v"(sl));
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
                 hi[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 lo[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
