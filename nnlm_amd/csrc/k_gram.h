@@ -131,8 +131,19 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
         b = t;
     }
     const size_t src = (size_t)a * KP + b;
+    // eight loads in flight, summed in slab order (the same sum as the one-load-at-a-time loop, ~4x sooner: the loop is load latency)
+    const size_t st = (size_t)KP * KP;
+    const double *q = slabs + src;
     double s = 0.0;
-    for (int i = 0; i < nslabs; i++) s += slabs[(size_t)i * KP * KP + src];
+    int i = 0;
+    for (; i + 8 <= nslabs; i += 8, q += 8 * st) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = q[u * st];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; i < nslabs; i++, q += st) s += *q;
     G[idx] = s;
 }
 

@@ -891,7 +891,8 @@ static int launch_xprod_generic(nnlm_handle *h, int which, const HalfPlan &p)
     return launch_xprod_generic_t<float>(h, which, p);
 }
 
-static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, int c_end, int *nslabs)
+// mb (optional): zeroed word that receives the bit pattern of max|Y| over the range (the split-fp16 copy's scale: no absmax pass)
+static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, int c_end, int *nslabs, unsigned *mb = nullptr)
 {
     int nb = (c_end - c_begin + GRAM_COLS_PER_BLOCK - 1) / GRAM_COLS_PER_BLOCK;
     if (nb < 1) nb = 1;
@@ -903,13 +904,14 @@ static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, in
         return;
     }
     switch (h->NKQ) {
-    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
-    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs); break;
+    case 1: gram_partial_kernel<1><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs, mb); break;
+    case 2: gram_partial_kernel<2><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs, mb); break;
+    case 3: gram_partial_kernel<3><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs, mb); break;
+    default: gram_partial_kernel<4><<<nb, 256, 0, h->stream>>>(Y, ld, c_begin, c_end, h->gslabs, mb); break;
     }
     const int KP = h->KP;
-    gram_reduce_kernel<<<(KP * KP + 255) / 256, 256, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
+    // (16 wavefronts per 64 entries, every 16th slab each: 5 us where the one-thread-per-entry sum over ~80 slabs took 20-25)
+    gram_fold_kernel<<<KP * KP / 64, 1024, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
     *nslabs = nb;
 }
 
@@ -1693,6 +1695,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         }
         h->sg_request = true; // this half-step's sweep leaves its slabs for the next one
     }
+    unsigned *gmb = nullptr;
     if (sg_strict && sg_which == ((which == 1) ? 0 : 1)) {
         ProfScope ps(h, P_GRAM, h->stream);
         gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
@@ -1705,14 +1708,21 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         const int lim = (which == 1) ? h->n : h->m;
         if (c1 > lim) c1 = lim;
         if (c0 > c1) c0 = c1;
-        if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs);
-        else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs);
+        // (one GPU, split-fp16 mode: the Gram pass also leaves max|fixed factor| for the split copies -- no absmax pass; the two
+        // words alternate as in the dense path above, each zeroed one half-step before its use)
+        if (h->x16 && !h->sharded && !generic_rank(h) && c0 == 0 && c1 == lim) {
+            gmb = h->maxbits + 1 + h->mb_par;
+            h->mb_par ^= 1;
+        }
+        if (which == 1) launch_gram(h, h->W64, h->npad, c0, c1, &gslabs, gmb);
+        else launch_gram(h, h->H64, h->mpad, c0, c1, &gslabs, gmb);
+        if (gmb) HIPCHK(h, hipMemsetAsync(h->maxbits + 1 + h->mb_par, 0, sizeof(unsigned), h->stream));
     }
     // 2. cross product slabs
     if (h->x16) {
         // (multi-GPU: the unpack of the previous half-step left max|fixed factor| behind -- no absmax pass)
         const int solved_by = (which == 1) ? 0 : 1; // the half-step that solved this half-step's fixed factor
-        unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : nullptr;
+        unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : gmb;
         prepare_factor16(h, which, mb);
         h->fixed_maxw = mb ? mb : h->maxbits;
     }
