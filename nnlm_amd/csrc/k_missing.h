@@ -458,12 +458,13 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
 // 32 rows per step, and  sum_r y_r y_r^T  over a step is  Hi Hi^T + (Hi Lo^T + Lo Hi^T) 2^-11  on v_mfma_f32_16x16x32_f16:
 // 3 products per upper tile pair, 16 cycles each for 32 rows -- 60 cycles of matrix pipe per four rows against 192 (tail form) /
 // 320 (padded) for v_mfma_f32_16x16x4_f32, and one set of index / address / LDS instructions per 32 rows instead of per 4.
-//   * gather: 8 global_load_lds_dwordx4 per step, one per 1 KB subtile [32 rows][16 halves] (plane hi / lo x coordinate tile):
-//     lane l fetches 16 bytes of row l / 2 -- the LDS image is the row-major [k][16] subtile ds_read_b64_tr_b16 wants (MFMA operand
-//     = 8 halves along k for the lane's coordinate: two transpose reads, conflict free);
-//   * row indices: one global_load_lds_dword per step (lane l: entry l / 2 of the step) into a 256-byte ring slot, read back with
-//     ds_read_b32 -- no VGPR destination, no compiler-visible VMEM: a step is "s_waitcnt vmcnt(0); issue the next step's gathers;
-//     multiply this step" with two 8 KB stage buffers per wavefront;
+//   * gather: 8 global_load_lds_dwordx4 per step, FOUR WHOLE ROWS each (lane l: a 16-byte chunk of row 4 j + l / 16: a request
+//     touches 8 cache lines; one [32 rows][16 halves] subtile per request touched 32 and ran into the L1's tag stage) into a
+//     row-major [32 rows][256 B] stage buffer, chunks swizzled through the GLOBAL address so that ds_read_b64_tr_b16 (MFMA operand
+//     = 8 halves along k for the lane's coordinate: two transpose reads) is conflict free -- details at the mapping below;
+//   * row indices: one global_load_lds_dword per step into a ring of four 256-byte slots, read back with ds_read_b32 -- no VGPR
+//     destination, no compiler-visible VMEM: a step is "s_waitcnt vmcnt(9); read this step's operands; issue the gathers of the
+//     step after the next one into the buffer just read out; multiply this step" with two 8 KB stage buffers per wavefront;
 //   * rows past the end of the list read row p of the split copy, which factor16c_kernel leaves zero;
 //   * fp32 accumulators folded into fp64 every 8 steps (256 rows), unscaled by 2^-2e at the end (e: the split copy's exponent).
 // The correction is ~the missing fraction of G, so 22-bit products keep G_j at ~1e-8 relative, as the fp32 form did.
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
     constexpr int NP = NKQ * (NKQ + 1) / 2;
     constexpr int STAGE = 8 * 1024;        // bytes: 2 planes x 4 coordinate tiles x [32][16] halves (the split copy always has 64 coordinates)
     __shared__ __attribute__((aligned(1024))) unsigned char stage_all[4][2][STAGE];
-    __shared__ int ibuf_all[4][2][64];
+    __shared__ int ibuf_all[4][4][64]; // ring of four index slots per wavefront (the indices run four steps ahead)
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
     const int col = col0 + blockIdx.x * 4 + wave;
     if (col >= ncols) return; // whole wave
@@ -509,16 +510,17 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
     // f(r) = (r & 3) | ((r >> 1) & 4) -- the eight rows one half-wavefront's transpose read touches have eight different f.
     const int r4 = lane >> 4;
     const unsigned goff0 = (unsigned)((((lane >> 1) & 7) ^ r4) << 5) | (unsigned)((lane & 1) << 4); // rows with bit 3 clear (j & 2 == 0)
-    auto issue_idx = [&](int g) { // entries 32 g + (lane & 31) of the list (the list array carries 64 words of slack) -> ring slot g & 1
-        const unsigned voff = (unsigned)(32 * g + (lane & 31)) * 4u;
-        const unsigned dst = lds_ibuf + (unsigned)(g & 1) * 256u;
+    auto issue_idx = [&](int g) { // entries 32 g + (lane & 31) of the list -> ring slot g & 3 (past the end: the last step's again)
+        const int ge = g < nst ? g : nst - 1;
+        const unsigned voff = (unsigned)(32 * ge + (lane & 31)) * 4u;
+        const unsigned dst = lds_ibuf + (unsigned)(g & 3) * 256u;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(ibase), "s"(dst) : "memory");
     };
     auto issue_rows = [&](int g) { // the 32 rows of step g into stage buffer g & 1, four rows per instruction
         const int rem = ulen - 32 * g - r4; // rows 4 j + r4 >= ulen - 32 g read the zero row
         int rows[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) rows[j] = ibuf[(g & 1) * 64 + 4 * j + r4];
+        for (int j = 0; j < 8; j++) rows[j] = ibuf[(g & 3) * 64 + 4 * j + r4];
         const unsigned dst = lds_stage + (unsigned)(g & 1) * (unsigned)STAGE;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -528,19 +530,23 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
         }
     };
     if (nst > 0) {
+        // TWO steps in flight with two stage buffers: a step's operands are in registers before its products start, so its buffer is
+        // refilled (step g + 2) in front of the products, not behind them.  Every step issues 1 index request (four steps ahead) + 8
+        // row requests, in this order -- "rows of step g have landed" is vmcnt(9), and the indices of step g + 2 are older than those rows.
         issue_idx(0);
         issue_idx(1);
+        issue_idx(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue_rows(0);
+        issue_idx(3);
+        issue_rows(1);
         // operand (plane pl, tile t) of the lane: halves k = 8 lg .. 8 lg + 7 of coordinate 16 t + l15: two transpose reads of
         // [4 rows][16 halves] blocks, lane (4 j + i) of a 16-lane group addressing row 8 lg + j (+ 4), halves 4 i .. 4 i + 3 of chunk
         // pair m = 4 pl + t, which sits at pair slot m ^ f(row): bits 5..7 of the lane's base hold f, so the address is base ^ (m << 5)
         const unsigned tr_lane = (unsigned)(8 * lg + (l15 >> 2)) * 256u + (unsigned)(((l15 >> 2) | ((lg & 1) << 2)) << 5) + (unsigned)(l15 & 3) * 8u;
         int since = 0;
         for (int g = 0; g < nst; g++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // rows of step g and indices of step g + 1 have landed
-            issue_idx(g + 2);                                 // (slot g & 1: its entries were consumed one step ago)
-            issue_rows(g + 1);                                // (past the end: zero rows into the other buffer, never multiplied)
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); // rows of step g (and indices up to step g + 2) have landed
             const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)stage + (unsigned)(g & 1) * (unsigned)STAGE + tr_lane;
             gh8 hi[NKQ], lo[NKQ];
 #pragma unroll
@@ -555,6 +561,9 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
                 hi[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 lo[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+            issue_idx(g + 4);  // (slot g & 3: its entries were consumed two steps ago)
+            issue_rows(g + 2); // buffer g & 1 has been read out (past the end: zero rows, never multiplied)
+            __builtin_amdgcn_sched_barrier(0);
             int pi = 0;
 #pragma unroll
             for (int a = 0; a < NKQ; a++)
