@@ -658,6 +658,33 @@ def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
             assert (s1, s2) == (it1, it2)
 
 
+@pytest.mark.parametrize("pname,prec,tol", PRECS)
+def test_missing_values_row_lists_around_the_gather_steps(pname, prec, tol):
+    """Row lists of exactly L rows for L around the multiples of the gather step (32 rows), of the ring depths (2 stage buffers, 4
+    index slots) and of the fp32 -> fp64 fold (256 rows) of na_gram_f16_kernel / the four-row groups of na_gram_lds_kernel
+    (k_missing.h); both sides of the half-way point, where the list switches from the missing to the present rows."""
+    rng = np.random.default_rng(4242)
+    lens = [0, 1, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 255, 256, 257, 288, 511, 512, 513, 600, 649, 650, 651, 700, 1299]
+    n, m, k = 1300, len(lens), 50
+    A = rng.random((n, m)) + 0.1
+    for j, L in enumerate(lens):
+        A[rng.choice(n, L, replace=False), j] = np.nan
+    W0, H0 = rng.random((n, k)), rng.random((k, m))
+    reg = [0.02, 0.01, 0.03]
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(k, W0, H0)
+        h.half_step(1, reg, 4, 1e-9, 1)
+        _, H1 = h.get_factors()
+        s1 = h.take_sweeps()
+        H_ref, it1 = ref.update(H0, W0.T.copy(), A, None, reg, 4, 1e-9, 1)
+        for j in range(m):
+            assert relF(H1[:, j], H_ref[:, j]) < 10 * tol, lens[j]
+        assert relF(H1, H_ref) < tol
+        if pname == "f64":
+            assert s1 == it1
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_small_shapes_with_missing_values(seed):
     """Randomised edge sweep of the NA path (row lists shorter than one gather step, contraction lengths below one tile, ranks that
