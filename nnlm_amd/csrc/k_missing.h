@@ -787,7 +787,15 @@ __global__ __launch_bounds__(256) void colsolve_strict_kernel(const SweepArgs a,
                 const double dd = tmp - x;
                 int2 dp = __builtin_bit_cast(int2, dd);
                 const int dlo = __builtin_amdgcn_readlane(dp.x, q), dhi = __builtin_amdgcn_readlane(dp.y, q);
-                mu = __builtin_fma(__builtin_bit_cast(double, int2{dlo, dhi}), g[q], mu); // mu += (tmp - x) * G.col(q)     (:26)
+                {
+                    // mu += (tmp - x) * G.col(q) (:26) as a product and a sum, like the reference's build (no FMA contraction on x86-64): with
+                    // nothing observed in a column and no regularisation G = NNLM_TINY I, mu = fl(TINY x), and the step to 0 must leave
+                    // mu = fl(TINY x) - fl(x TINY) = 0 exactly -- a fused multiply-add leaves the product's rounding error, which the next
+                    // sweep turns into 1e-17 of dust and, half of the time, one more counted sweep than the reference runs
+#pragma clang fp contract(off)
+                    const double prod = __builtin_bit_cast(double, int2{dlo, dhi}) * g[q];
+                    mu = mu + prod;
+                }
                 int2 xp = __builtin_bit_cast(int2, xn), tp = __builtin_bit_cast(int2, tmp);
                 asm volatile("s_mov_b32 vcc_lo, %4\n\ts_mov_b32 vcc_hi, %5\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
                              : "+v"(xp.x), "+v"(xp.y)
