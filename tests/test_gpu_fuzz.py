@@ -1,7 +1,7 @@
 """Randomised whole-driver parity: nnlm_amd.c_nnmf (the C ABI of libnnlm_mi355x.so) against the oracle's ref.c_nnmf
 (oracle/nnlm_ref.c, the restatement of src/nnmf.cpp:4-219) over random shapes, ranks, the four methods, missing values, masks,
 regularisation, trace strides and inner iteration limits -- the combinations the hand-written cases of test_gpu_parity.py do not
-enumerate.  NNLM_FUZZ_SEEDS (default 24) sets the number of cases per mode; the round's deep run used 300 (568 agree, 32 degenerate).
+enumerate.  NNLM_FUZZ_SEEDS (default 24) sets the number of cases per mode; the round's deep run used 300 (900 cases with test_random_nnlm_runs: 863 agree, 37 degenerate).
 
 Strict mode: factors at 1e-9 relative Frobenius, iteration counts, trace lengths and sweep counts (average_epoch) exact.
 F32 mode: north_star's 1e-4 on well-conditioned cases (rank at most a third of the smaller dimension, at most 30 % missing)."""
@@ -26,6 +26,8 @@ def make_case(seed, well_conditioned):
     n, m = int(rng.integers(2, 400)), int(rng.integers(2, 400))
     if seed % 7 == 0:
         n = int(rng.integers(400, 1500))  # more than one cross-product tile / gather step
+    if seed % 11 == 0:
+        n, m = int(rng.integers(1500, 4000)), int(rng.integers(400, 2500))  # several tiles, split-K slabs and sweep workgroups each way
     kmax = max(1, min(n, m) // 3) if well_conditioned else min(n, m, 70)
     k = int(rng.integers(1, min(kmax, 64 if well_conditioned or seed % 5 else 70) + 1))
     method = 1 + seed % 4
@@ -118,3 +120,41 @@ def test_random_driver_runs_f32_mode(monkeypatch, seed):
     assert relF(r["W"], o["W"]) < 1e-4 and relF(r["H"], o["H"]) < 1e-4, (relF(r["W"], o["W"]), relF(r["H"], o["H"]), d)
     assert np.allclose(r["mse_error"], o["mse_error"], rtol=1e-3, atol=1e-12), d
     assert np.allclose(r["target_error"], o["target_error"], rtol=1e-3, atol=1e-9), d
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_nnlm_runs(monkeypatch, seed):
+    """c_nnlm (src/nnlm.cpp:4-53: the half-step solver on y ~ x beta, rank = ncol(x)) with random predictors, responses with and
+    without missing values, masks, given / default starts and the four methods; strict mode, sweep counts exact."""
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    rng = np.random.default_rng(55000 + seed)
+    n, p, q = int(rng.integers(3, 600)), int(rng.integers(1, 80)), int(rng.integers(1, 40))
+    if seed % 3 == 0:
+        p = int(rng.integers(1, min(n, 20) + 1))  # (a well-determined regression)
+    method = 1 + seed % 4
+    x = rng.random((n, p)) + 0.02
+    b = rng.random((p, q)) * (rng.random((p, q)) > 0.3)
+    b[rng.integers(0, p, q), np.arange(q)] += 0.3  # (no response without a predictor: see the skip below)
+    y = x @ b + 0.02 * rng.random((n, q)) + 0.01
+    if (seed // 4) % 3 == 1:
+        y[rng.random((n, q)) < [0.05, 0.3, 0.7][seed % 3]] = np.nan
+    mask = (rng.random((p, q)) < 0.15) if (seed // 2) % 3 == 1 else None
+    b0 = None if seed % 5 == 0 else rng.random((p, q)) + 0.01
+    if mask is not None and b0 is not None:
+        b0[mask] = 0.0
+    alpha = [[0, 0, 0], [0.01, 0, 0.001], [0.02, 0.01, 0.03]][seed % 3]
+    max_iter = int(rng.integers(1, 30)) if method in (1, 2) else int(rng.integers(1, 6))
+    r = nnlm_amd.c_nnlm(x, y, alpha, mask, b0, max_iter, 1e-10, 1, method)
+    o = ref.c_nnlm(x, y, alpha, mask, b0, max_iter, 1e-10, 1, method)
+    d = dict(n=n, p=p, q=q, method=method, na=float(np.isnan(y).mean()), mask=mask is not None, b0=b0 is not None, alpha=alpha, max_iter=max_iter)
+    if not np.isfinite(o["coefficient"]).all():
+        pytest.skip("the oracle's own result is not finite")
+    free = np.ones((p, q), bool) if mask is None else ~mask
+    if method == 3 and ((o["coefficient"] == 0) | ~free).all(axis=0).any():
+        # every free coordinate of a column at exactly zero under the KL coordinate descent: its state vector is cancellation noise
+        # of either sign and the next sweep's quotients w / (noise + 1e-16) are decided by the summation order (DESIGN 2)
+        pytest.skip("a column of the KL coordinate descent went to zero: not reproducible")
+    assert relF(r["coefficient"], o["coefficient"]) < 1e-9, (relF(r["coefficient"], o["coefficient"]), d)
+    assert r["n_iteration"] == o["n_iteration"], (r["n_iteration"], o["n_iteration"], d)
+    if mask is not None and b0 is not None:
+        assert np.all(r["coefficient"][mask] == 0)
