@@ -14,6 +14,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers import relF  # noqa: E402
 import nnlm_amd  # noqa: E402
+from nnlm_amd import _lib  # noqa: E402
 from oracle import ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -158,3 +159,75 @@ def test_random_nnlm_runs(monkeypatch, seed):
     assert r["n_iteration"] == o["n_iteration"], (r["n_iteration"], o["n_iteration"], d)
     if mask is not None and b0 is not None:
         assert np.all(r["coefficient"][mask] == 0)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_virtual_rank_runs(monkeypatch, seed):
+    """The multi-GPU arithmetic with 2 - 8 virtual ranks on one device (the host standing in for ncclAllReduce / ncclAllGather,
+    nnlm_debug_phase / nnlm_debug_exchange) over random shapes -- ranks with few or no columns included --, methods, missing values,
+    masks and both forms of the dense half-step: two iterations, every rank must end with identical factors, equal to the
+    single-rank run up to the summation order of the split."""
+    rng = np.random.default_rng(91000 + seed)
+    world = [2, 3, 4, 8][seed % 4]
+    n, m = int(rng.integers(8, 1400)), int(rng.integers(8, 900))
+    k = int(rng.integers(1, min(n, m, 64) + 1)) if seed % 9 else int(rng.integers(65, 72))
+    k = min(k, n, m)
+    method = 1 + (seed // 4) % 4
+    na = (seed // 2) % 3 == 1
+    reduce_form = (seed % 2 == 1) and method <= 2 and not na
+    if reduce_form:
+        monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
+    else:
+        monkeypatch.delenv("NNLM_SHARD_DENSE", raising=False)
+    Wp, Hp = rng.random((n, k + 2)) ** 2 + 0.05, rng.random((k + 2, m)) ** 2 + 0.05
+    A = Wp @ Hp / (k + 2) * 4 + 0.02 * rng.random((n, m)) + 0.01
+    if na:
+        A[rng.random((n, m)) < 0.15] = np.nan
+    sc = 2.0 / np.sqrt(k + 2)
+    W0, H0 = Wp[:, :k] * sc * (0.7 + 0.6 * rng.random((n, k))), Hp[:k, :] * sc * (0.7 + 0.6 * rng.random((k, m)))
+    Wm = (rng.random((n, k)) < 0.05) if seed % 3 == 0 else None
+    Hm = (rng.random((k, m)) < 0.05) if seed % 6 == 0 else None
+    if Wm is not None:
+        W0[Wm] = 0.0
+    if Hm is not None:
+        H0[Hm] = 0.0
+    alpha, beta = [[0, 0, 0], [0.02, 0.01, 0.03]][seed % 2], [[0.01, 0, 0.01], [0, 0, 0]][(seed // 2) % 2]
+    inner = int(rng.integers(1, 6)) if method < 3 else int(rng.integers(1, 3))
+    d = dict(world=world, shape=(n, m), k=k, method=method, na=na, reduce=reduce_form, masks=(Wm is not None, Hm is not None), inner=inner)
+    for pname, prec in (("f64", _lib.PREC_F64), ("f32", _lib.PREC_F32)):
+        with nnlm_amd.Handle(0, prec) as h1:
+            h1.set_matrix(A)
+            h1.set_factors(k, W0, H0, Wm, Hm)
+            h1.iterate(2, alpha, beta, inner, 1e-9, method)
+            W_ref, H_ref = h1.get_factors()
+            sw_ref = h1.take_sweeps()
+            mse_ref = h1.errors()[0]
+        hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
+        try:
+            for rk, h in enumerate(hs):
+                h.comm_init(None, rk, world)
+                h.set_matrix(A)
+                h.set_factors(k, W0, H0, Wm, Hm)
+            for _ in range(2):
+                for which, reg in ((0, alpha), (1, beta)):
+                    for h in hs:
+                        h.debug_phase(which, 1, reg, inner, 1e-9, method)
+                    if reduce_form:
+                        _lib.debug_exchange(hs, which, 1)
+                    for h in hs:
+                        h.debug_phase(which, 2, reg, inner, 1e-9, method)
+                    _lib.debug_exchange(hs, which, 2)
+                    for h in hs:
+                        h.debug_phase(which, 3, reg, inner, 1e-9, method)
+            res = [h.get_factors() for h in hs]
+            sweeps = sum(h.take_sweeps() for h in hs)
+            mse = sum(h.errors()[0] for h in hs)
+        finally:
+            for h in hs:
+                h.close()
+        for W, H in res[1:]:
+            assert np.array_equal(W, res[0][0]) and np.array_equal(H, res[0][1]), (pname, d)
+        t = 1e-10 if pname == "f64" else (2e-5 if method < 3 else 1e-4)
+        assert relF(res[0][0], W_ref) < t and relF(res[0][1], H_ref) < t, (pname, relF(res[0][0], W_ref), relF(res[0][1], H_ref), d)
+        assert abs(sweeps - sw_ref) <= (0 if pname == "f64" else 2 + sw_ref // 1000), (pname, sweeps, sw_ref, d)
+        assert abs(mse - mse_ref) < (1e-9 if pname == "f64" else 1e-5) * mse_ref, (pname, mse, mse_ref, d)
