@@ -1,7 +1,8 @@
 """Randomised whole-driver parity: nnlm_amd.c_nnmf (the C ABI of libnnlm_mi355x.so) against the oracle's ref.c_nnmf
 (oracle/nnlm_ref.c, the restatement of src/nnmf.cpp:4-219) over random shapes, ranks, the four methods, missing values, masks,
 regularisation, trace strides and inner iteration limits -- the combinations the hand-written cases of test_gpu_parity.py do not
-enumerate.  NNLM_FUZZ_SEEDS (default 24) sets the number of cases per mode; the round's deep run used 300 (900 cases with test_random_nnlm_runs: 863 agree, 37 degenerate).
+enumerate.  NNLM_FUZZ_SEEDS (default 16) sets the number of cases per test; the round's deep run used 300 (900 cases with test_random_nnlm_runs: 863 agree, 37 degenerate;
+120 seeds of the virtual-rank runs and 150 of the stopping rule: all agree, 5 degenerate).
 
 Strict mode: factors at 1e-9 relative Frobenius, iteration counts, trace lengths and sweep counts (average_epoch) exact.
 F32 mode: north_star's 1e-4 on well-conditioned cases (rank at most a third of the smaller dimension, at most 30 % missing)."""
@@ -19,7 +20,7 @@ from oracle import ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = int(os.environ.get("NNLM_FUZZ_SEEDS", "24"))
+SEEDS = int(os.environ.get("NNLM_FUZZ_SEEDS", "16"))
 
 
 def make_case(seed, well_conditioned):
@@ -231,3 +232,30 @@ def test_random_virtual_rank_runs(monkeypatch, seed):
         assert relF(res[0][0], W_ref) < t and relF(res[0][1], H_ref) < t, (pname, relF(res[0][0], W_ref), relF(res[0][1], H_ref), d)
         assert abs(sweeps - sw_ref) <= (0 if pname == "f64" else 2 + sw_ref // 1000), (pname, sweeps, sw_ref, d)
         assert abs(mse - mse_ref) < (1e-9 if pname == "f64" else 1e-5) * mse_ref, (pname, mse, mse_ref, d)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_driver_stopping_rule(monkeypatch, seed):
+    """The stopping rule of the driver (src/nnmf.cpp:142-158: relative change of the target error between two trace points below
+    rel.tol) on random problems: the strict mode must stop at the reference's iteration with the reference's traces; the F32 mode
+    may differ by one trace interval when the decisive quotient sits within its 1e-4 of the threshold."""
+    c = make_case(seed, well_conditioned=True)
+    c["max_iter"] = 80
+    rel_tol = [1e-2, 1e-3, 1e-4][seed % 3]
+    if degenerate(dict(c, max_iter=3)):
+        pytest.skip("a factor dies on the way: not reproducible (see make_case)")
+    args = (c["A"], c["k"], c["W0"], c["H0"], c["Wm"], c["Hm"], c["alpha"], c["beta"], c["max_iter"], rel_tol, 1, 0, False, c["inner"], 1e-9,
+            c["method"], c["trace"])
+    o = ref.c_nnmf(*args)
+    d = dict(describe(c), rel_tol=rel_tol, n_iteration=o["n_iteration"])
+    monkeypatch.setenv("NNLM_PRECISION", "f64")
+    r = nnlm_amd.c_nnmf(*args)
+    assert r["n_iteration"] == o["n_iteration"] and r["warning"] == o["warning"], (r["n_iteration"], d)
+    assert r["target_error"].shape == o["target_error"].shape and np.allclose(r["target_error"], o["target_error"], rtol=1e-7, atol=1e-12), d
+    assert np.array_equal(r["average_epoch"], o["average_epoch"]), d
+    assert relF(r["W"], o["W"]) < 1e-8 and relF(r["H"], o["H"]) < 1e-8, (relF(r["W"], o["W"]), relF(r["H"], o["H"]), d)
+    monkeypatch.setenv("NNLM_PRECISION", "f32")
+    r = nnlm_amd.c_nnmf(*args)
+    assert abs(r["n_iteration"] - o["n_iteration"]) <= c["trace"], (r["n_iteration"], d)
+    if r["n_iteration"] == o["n_iteration"]:
+        assert np.allclose(r["target_error"], o["target_error"], rtol=1e-3, atol=1e-9), d
