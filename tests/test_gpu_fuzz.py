@@ -234,7 +234,7 @@ def test_random_virtual_rank_runs(monkeypatch, seed):
         assert abs(mse - mse_ref) < (1e-9 if pname == "f64" else 1e-5) * mse_ref, (pname, mse, mse_ref, d)
 
 
-@pytest.mark.parametrize("seed", range(SEEDS))
+@pytest.mark.parametrize("seed", range(max(1, SEEDS // 2)))  # (up to 80 iterations each: the slow one)
 def test_random_driver_stopping_rule(monkeypatch, seed):
     """The stopping rule of the driver (src/nnmf.cpp:142-158: relative change of the target error between two trace points below
     rel.tol) on random problems: the strict mode must stop at the reference's iteration with the reference's traces; the F32 mode
