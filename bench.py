@@ -162,7 +162,7 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                 # (one wavefront per SIMD: dependent-issue latency of the chain; two: the matrix pipe, which a second wavefront cannot overlap)
                 fl = inner * (cols / world) * k * (2 * k + 8)
                 knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else \
-                      ("sweep_scd_q_kernel" if s == 4 else "sweep_scd_wg_kernel")
+                      "sweep_scd_q_kernel"  # (both modes since round 3: <.., STRICT = false> / <.., STRICT = true>)
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
                         "flops = inner*cols*k*(2k+8)")
@@ -178,7 +178,10 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                     note += (" (fp64 vector peak) + 2k^2 per missing entry for the per-column Grams ("
                              + ("3 split-fp16 products per flop on v_mfma_f32_16x16x32_f16: a third of the 2.5 PF dense fp16 peak" if s == 4 else "fp64 MFMA peak")
                              + "); peak = total flops / (sum of the two floors)")
-                classes[nm] = dict(bound="mfma", kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12,
+                # dense sweep: a loop-carried recurrence, bound by the dependent-issue latency of its 4 x ceil(k/4) x inner stages per
+                # column (SURVEY 8d grants it no roofline); the fraction of the fp64 matrix peak is reported for scale, not as its bound.
+                # NA flow: per-column Grams on the matrix cores + the solver: "mfma".
+                classes[nm] = dict(bound=("mfma" if cfg["na"] else "latency"), kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12,
                                    pmc=(None if cfg["na"] else "sweep_scd_q_kernel"), note=note)
     else:
         for nm in ("sweep_h", "sweep_w"):
@@ -220,7 +223,9 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
     return roofline, secondary, all_blocks, shares
 
 
-SCOPES = ("xprod_h", "xprod_w", "xprod_w_err", "gram", "sweep_h", "sweep_w", "errors")
+SCOPES = ("xprod_h", "xprod_w", "xprod_w_err", "gram", "sweep_h", "sweep_w", "errors", "allgather", "allreduce", "unpack")
+# (allgather / allreduce: the RCCL collective of a sharded half-step between two HIP events on the stream it is enqueued on -- includes
+#  the wait for the slowest rank; unpack: shard_unpack_kernel + the sum of the ranks' Gram partial sums)
 
 
 def profile_scopes(h):
@@ -354,6 +359,15 @@ def main():
     prof_elapsed = time.perf_counter() - t0
     kern = profile_scopes(h)
     h.profile_enable(False)
+    # per-phase time of a step, MAX over ranks (one SCALE line then shows where the step goes: what shards, what every rank repeats,
+    # what the collectives cost)
+    phase_tot = [kern[nm]["total_ms"] for nm in SCOPES]
+    if dist is not None:
+        import torch
+        tt = torch.tensor(phase_tot, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        phase_tot = [float(v) for v in tt]
+    phases_ms = {nm: v / args.steps for nm, v in zip(SCOPES, phase_tot) if v > 0}
 
     # GPU mse after `cpu_iters` iterations from the warmed state (what the CPU sample reproduces)
     gpu_check = None
@@ -436,6 +450,9 @@ def main():
         "step": step,
         "cpu_baseline": cpu,
         "mse_check": mse_check,
+        "phases_ms": dict(phases_ms, note="HIP-event time per step of each phase in the profiled replay, max over ranks; 'gram' = Gram + split copy + "
+                                           "sweep operand image; N > 1: 'allgather' / 'allreduce' = the RCCL call between two events on its stream "
+                                           "(includes waiting for the slowest rank), 'unpack' = scatter of the gathered slabs (+ split copy + Gram sum)"),
         "kernels": kern,
         "kernel_time_share": shares,
         "profiled_ms_per_step": 1e3 * prof_elapsed / args.steps,

@@ -118,6 +118,20 @@ __global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restric
     gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
 }
 
+// The same fold for the Gram partial sums that travel behind a rank's packed slab (multi-GPU, dense SCD, column form), plus the
+// rank's max|x| -- left by its sweep as the bit pattern of a float in *maxword -- as ONE more double behind them (G[KP * KP]);
+// the word is cleared for the next sweep.  The unpack on every rank then knows max|factor| BEFORE it reads a single entry and
+// writes the split-fp16 copy itself (shard_unpack_kernel).
+__global__ __launch_bounds__(1024) void gram_fold_tail_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
+                                                              unsigned *__restrict__ maxword)
+{
+    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        G[(size_t)KP * KP] = (double)__uint_as_float(*maxword);
+        *maxword = 0u;
+    }
+}
+
 // G[a][b] = sum over slabs (fixed order); entries of lower tiles are read from the mirrored upper tile.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ slabs, int nslabs, int KP,
                                                           double *__restrict__ G)
@@ -160,30 +174,57 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restri
 }
 
 // Multi-GPU: scatter the all-gathered per-rank slabs of the updated factor back into the resident layouts.
-// packed [nranks][KP][cpr] with KP = the rows that travelled (the caller passes k: the padding rows of a slab are not gathered);
+// packed: per rank a [KPt][cpr] slab (KPt = k: the padding rows of a slab are not gathered) + its tail, rank_stride doubles apart;
 // rank rr holds columns rr*cpr .. of the factor; X [KP][ldx] master; op = GEMM operand copy
-// (op_mode 1: [KP][op_ld] same layout as X, 2: [col][op_ld] kq fastest, 0: none), element type float or double.
-// maxw (optional): max |x| over the factor as the bit pattern of a float (what absmax_f64_kernel computes), for the split-fp16 copy of
-// the NEXT half-step, whose fixed factor this is -- the unpack reads every entry anyway.  Zeroed by the caller.
-// rank_stride: doubles between the payloads of two ranks (KP * cpr, + the Gram partial sums that travel behind the slab: below).
-__global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KP, int cpr, int k,
+// (op_mode 1: [KP][op_ld] same layout as X, 0: none), element type float or double.
+// The grid covers KProws x (nranks * cpr) entries: KProws = k without the split copy below, the padded rank 16 NKQ with it.
+// maxw (optional): receives max |x| over the factor as the bit pattern of a float (what absmax_f64_kernel computes), for the
+// split-fp16 copies of the NEXT half-step, whose fixed factor this is.
+//   tail_max_off == (size_t)-1: found here while the entries are read (atomicMax; the caller zeroed the word);
+//   otherwise packed[r * rank_stride + tail_max_off] holds rank r's own max (gram_fold_tail_kernel): max|factor| is known up
+//   front, and with Y16 != NULL the kernel also writes the split-fp16 copy of the factor [KProws][plen/64][2][64] (k_xprod16.h),
+//   zero padded, and its exponent -- the next half-step then starts with its cross product (no absmax pass, no factor16_kernel).
+__device__ static inline int unpack_split16_exponent(float maxabs) // = split16_exponent (k_xprod16.h includes this file)
+{
+    if (!(maxabs > 0.0f) || maxabs > 3.0e38f) return 0;
+    int ex;
+    (void)frexpf(maxabs, &ex);
+    return 15 - ex;
+}
+__global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restrict__ packed, int nranks, int KProws, int cpr, int k,
                                                            int ncols, double *__restrict__ X, int ldx, void *__restrict__ op,
-                                                           int op_mode, int op_ld, int op_f64, unsigned *__restrict__ maxw, size_t rank_stride)
+                                                           int op_mode, int op_ld, int op_f64, unsigned *__restrict__ maxw, size_t rank_stride,
+                                                           size_t tail_max_off, uint32_t *__restrict__ Y16, int plen, int *__restrict__ exp_out)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t per_rank = (size_t)KP * cpr;
-    float mx = 0.0f;
-    bool live = e < per_rank * nranks;
-    int q = 0, col = 0;
-    if (live) {
-        const int rr = (int)(e / per_rank);
+    const size_t per_rank = (size_t)KProws * cpr;
+    bool in_grid = e < per_rank * nranks;
+    bool live = in_grid;
+    int q = 0, col = 0, rr = 0, c = 0;
+    if (in_grid) {
+        rr = (int)(e / per_rank);
         q = (int)((e % per_rank) / cpr);
-        col = rr * cpr + (int)(e % cpr);
+        c = (int)(e % cpr);
+        col = rr * cpr + c;
         live = q < k && col < ncols;
     }
-    const double v = live ? packed[(e / per_rank) * rank_stride + e % per_rank] : 0.0;
-    if (maxw) { // (whole wavefronts stay together for the reduction)
-        mx = fabsf((float)v);
+    const double v = live ? packed[(size_t)rr * rank_stride + (size_t)q * cpr + c] : 0.0;
+    if (tail_max_off != (size_t)-1) {
+        float mx = 0.0f;
+        for (int r = 0; r < nranks; r++) mx = fmaxf(mx, (float)packed[(size_t)r * rank_stride + tail_max_off]);
+        if (e == 0) {
+            if (maxw) *maxw = __float_as_uint(mx);
+            if (exp_out) *exp_out = unpack_split16_exponent(mx);
+        }
+        if (Y16 && in_grid && col < plen) {
+            const float x = (float)v * ldexpf(1.0f, unpack_split16_exponent(mx));
+            const _Float16 hi = (_Float16)x, lo = (_Float16)((x - (float)hi) * 2048.0f); // split16()
+            _Float16 *row = (_Float16 *)(Y16 + (size_t)q * plen + (size_t)(col >> 6) * 64);
+            row[col & 63] = hi;
+            row[64 + (col & 63)] = lo;
+        }
+    } else if (maxw) { // (whole wavefronts stay together for the reduction)
+        float mx = fabsf((float)v);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxw, __float_as_uint(mx));

@@ -391,9 +391,9 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
     }
 }
 
-// (masked with k > 56: one wavefront per SIMD rather than spills)
+// (masked with k > 56 -- strict mode: k > 52 --: one wavefront per SIMD rather than spills)
 template <int NT, int NB, bool HAS_MASK, bool STRICT>
-__global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && NB >= 15) ? 1 : 2)) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
+__global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && (NB >= 15 || (STRICT && NB >= 14))) ? 1 : 2)) void sweep_scd_q_kernel(const SweepArgs a, const double *__restrict__ img)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sq_smem[]; // sweepq_lds_bytes(KP, NB, STRICT)
     sweepq16_body<NT, NB, HAS_MASK, STRICT>(a, img, sq_smem);

@@ -35,9 +35,11 @@
 
 static thread_local std::string g_last_error;
 
-enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_XPROD_W_ERR, P_COUNT };
-// ("xprod_w_err": W half-step cross products that also evaluate the error sums -- the fused launches have a scope of their own)
-static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors", "xprod_w_err"};
+enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_XPROD_W_ERR, P_ALLGATHER, P_ALLREDUCE, P_UNPACK, P_COUNT };
+// ("xprod_w_err": W half-step cross products that also evaluate the error sums -- the fused launches have a scope of their own;
+//  "allgather" / "allreduce": the RCCL collective of a sharded half-step between two events on the stream it is enqueued on;
+//  "unpack": shard_unpack_kernel + the sum of the ranks' Gram partial sums behind it)
+static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors", "xprod_w_err", "allgather", "allreduce", "unpack"};
 
 struct ProfRec {
     int id;
@@ -61,6 +63,7 @@ struct nnlm_handle {
     bool dense_cols = true;     // multi-GPU form of the dense square-loss half-step (half_step): column-sharded (true) or all-reduce
     int upk_max_for = -1;       // multi-GPU: the half-step (0: W, 1: H) whose unpack left max|factor| in maxbits[6 + which], or -1
     int gshard_for = -1;        // multi-GPU: the factor (0: W, 1: H) whose Gram the last unpack summed into Graw from the ranks' partial sums, or -1
+    int y16_for = -1;           // multi-GPU: the factor whose split-fp16 copy (and exponent, scal_exp[1]) the last unpack left in Y16, or -1
     size_t pack_tail = 0;       // doubles behind the k x cpr slab in the packed payload of the current half-step (KP * KP Gram partial sums, or 0)
     unsigned *fixed_maxw = nullptr; // word holding max|fixed factor| of the half-step in progress (split-fp16 copies)
     double n_non_missing = 0.0, kl_const = 0.0;
@@ -111,8 +114,9 @@ struct nnlm_handle {
     // split-fp16 cross products (k_xprod16.h; F32 mode, single GPU): A16 [mpad][npad], A16T [npad][mpad], Y16 [KP][max(npad,mpad)]
     bool x16 = false;
     uint32_t *A16 = nullptr, *A16T = nullptr, *Y16 = nullptr;
-    unsigned *maxbits = nullptr; // device [8]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter, [6],[7] shard_unpack_kernel (W, H),
-                                 // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_q.h)
+    unsigned *maxbits = nullptr; // device [16]: bit patterns of max|factor|: [0] absmax_f64_kernel, [1],[2] alternately gram_partial_kernel, [3] block counter, [6],[7] shard_unpack_kernel (W, H),
+                                 // [4],[5] alternately the fast sweep kernel's own max of what it solved (k_sweep_q.h), [8] the same for a rank's
+                                 // column shard (travels behind its packed slab: gram_fold_tail_kernel clears it)
     // What the fast sweep leaves behind for the next half-step (dense one-GPU split-fp16 path): max|x| in maxbits[4 + sg_par] and
     // sg_nslabs Gram partial sums (one per workgroup) in sg_slabs.  sg_which: the factor they describe (1 = H, 0 = W, -1 = none).
     int sg_which = -1, sg_par = 0, sg_nslabs = 0;
@@ -153,6 +157,29 @@ static int fail(nnlm_handle *h, int code, const char *fmt, ...)
     do {                                                                                                             \
         hipError_t e__ = (call);                                                                                     \
         if (e__ != hipSuccess) return fail(h, NNLM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// Dynamic LDS beyond 64 KB must be granted per kernel.  The launch helpers are void: a refusal is remembered here and reported by the
+// next LAUNCHCHK (every half-step / error block ends with one), together with whatever the launch itself then raised.
+static thread_local hipError_t g_attr_err = hipSuccess;
+static thread_local const char *g_attr_what = "";
+static inline void set_dyn_lds(const void *fn, int lds, const char *what)
+{
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess && g_attr_err == hipSuccess) {
+        g_attr_err = e;
+        g_attr_what = what;
+    }
+}
+#define LAUNCHCHK(h)                                                                                                              \
+    do {                                                                                                                          \
+        if (g_attr_err != hipSuccess) {                                                                                           \
+            const hipError_t ea__ = g_attr_err;                                                                                   \
+            g_attr_err = hipSuccess;                                                                                              \
+            (void)hipGetLastError();                                                                                              \
+            return fail(h, NNLM_ERR_HIP, "hipFuncSetAttribute(%s, MaxDynamicSharedMemorySize) failed: %s", g_attr_what, hipGetErrorString(ea__)); \
+        }                                                                                                                         \
+        HIPCHK(h, hipGetLastError());                                                                                             \
     } while (0)
 
 // split-fp16 cross products (k_xprod16.h): THE cross products of the F32 mode
@@ -282,17 +309,28 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         hipHostMalloc(&h->host_res, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc(&h->sweeps_tmp, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->sweepq_img, sweepq_img_doubles(16, true) * sizeof(double)) != hipSuccess ||
-        hipMalloc(&h->maxbits, 8 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&h->maxbits, 16 * sizeof(unsigned)) != hipSuccess || hipMalloc(&h->scal_exp, 4 * sizeof(int)) != hipSuccess) {
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
     hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
     hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
-    hipMemsetAsync(h->maxbits, 0, 8 * sizeof(unsigned), h->stream);
+    hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream);
     hipStreamSynchronize(h->stream);
     h->x16 = x16_enabled(precision);
     *out = h;
     return NNLM_OK;
+}
+
+// Everything a half-step may find left behind by the previous one describes the factors as the library last wrote them: any other
+// writer of the factors (nnlm_set_factors) or of the exchange (nnlm_comm_init) calls this.
+static void invalidate_factor_caches(nnlm_handle *h)
+{
+    h->upk_max_for = -1;
+    h->gshard_for = -1;
+    h->y16_for = -1;
+    h->sg_which = h->sg_other = -1;
+    h->pack_ready = false;
 }
 
 static void free_factors(nnlm_handle *h)
@@ -430,8 +468,8 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
     if (cols_per_chunk > m) cols_per_chunk = m;
     double *stage = nullptr;
     HIPCHK(h, hipMalloc(&stage, (size_t)cols_per_chunk * n * 8));
-    std::vector<double> hp(2 * prep_blocks);
-    double cnt = 0.0, klc = 0.0;
+    std::vector<double> hp(3 * prep_blocks);
+    double cnt = 0.0, klc = 0.0, over = 0.0;
     int rc = NNLM_OK;
     for (int j0 = 0; j0 < m && rc == NNLM_OK; j0 += cols_per_chunk) {
         const int cols = (m - j0 < cols_per_chunk) ? m - j0 : cols_per_chunk;
@@ -442,16 +480,22 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
             prep_convert_kernel<double><<<grid, PREP_BLOCK, 0, h->stream>>>(stage, n, cols, j0, (double *)h->A, h->npad, h->miss, h->partials);
         else
             prep_convert_kernel<float><<<grid, PREP_BLOCK, 0, h->stream>>>(stage, n, cols, j0, (float *)h->A, h->npad, h->miss, h->partials);
-        e = hipMemcpyAsync(hp.data(), h->partials, 2 * prep_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        e = hipMemcpyAsync(hp.data(), h->partials, 3 * prep_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { rc = fail(h, NNLM_ERR_HIP, "prep pass failed: %s", hipGetErrorString(e)); break; }
         for (size_t b = 0; b < prep_blocks; b++) {
-            cnt += hp[2 * b];
-            klc += hp[2 * b + 1];
+            cnt += hp[3 * b];
+            klc += hp[3 * b + 1];
+            over += hp[3 * b + 2];
         }
     }
     hipFree(stage);
     if (rc != NNLM_OK) return rc;
+    if (over > 0.0) {
+        free_matrix(h);
+        return fail(h, NNLM_ERR_UNSUPPORTED, "%.0f finite entries of A exceed the fp32 range (|a| > 3.4e38): the fp32-operand mode cannot hold them; "
+                                             "use the strict fp64 mode (NNLM_PREC_F64, the default of nnlm_c_nnmf / nnlm_c_nnlm)", over);
+    }
     h->n_non_missing = cnt;
     h->any_missing = cnt != (double)n * (double)m;
     h->kl_const = klc / cnt; // mean((A+eps) log(A+eps) - A) over finite entries, src/nnmf.cpp:70,73
@@ -464,6 +508,11 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         float mx;
         memcpy(&mx, &mb, 4);
+        if (mx > 0.0f && mx < 7.8886090522101181e-31f) { // 2^-100: entries 2^-26 below the largest one are fp32 denormals
+            free_matrix(h);
+            return fail(h, NNLM_ERR_UNSUPPORTED, "max |A| = %.3g is too close to the bottom of the fp32 range for the fp32-operand mode (entries would "
+                                                 "be denormal or flushed to zero); rescale A or use the strict fp64 mode", (double)mx);
+        }
         const int eA = split16_exponent(mx);
         HIPCHK(h, hipMemcpyAsync(h->scal_exp, &eA, sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMalloc(&h->A16, cnt_a * 4 + 4096));
@@ -473,7 +522,7 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
         dim3 gt(h->npad / 64, h->mpad / 64);
         a16_transpose_kernel<<<gt, 256, 0, h->stream>>>((const float *)h->A, h->npad, h->npad, h->mpad, scale, h->A16T);
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
+        LAUNCHCHK(h);
     }
     if (h->any_missing) { // row-wise view of the missing mask for the W half-step
         const size_t wordsT = (size_t)h->npad * (h->mpad / 32);
@@ -589,8 +638,8 @@ extern "C" int nnlm_set_factors(nnlm_handle *h, unsigned k_, const double *W, co
     if (k < 1) return fail(h, NNLM_ERR_ARG, "nnlm_set_factors: rank k must be >= 1");
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
-    h->upk_max_for = -1;
-    h->gshard_for = -1;
+    invalidate_factor_caches(h);
+    HIPCHK(h, hipMemset(h->maxbits + 8, 0, sizeof(unsigned)));
     if (k != h->k) {
         free_factors(h);
         h->k = k;
@@ -693,7 +742,7 @@ static void launch_xprod(nnlm_handle *h, int which, const HalfPlan &p)
     const int KP = 16 * (NKQ + (KT > 0 ? 1 : 0)); // = h->KP
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(KP);
-    hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set_dyn_lds((const void *)xprod_tn_kernel<T, NKQ, KT>, lds, "xprod_tn_kernel");
     if (which == 1)
         xprod_tn_kernel<T, NKQ, KT><<<grid, XPROD_THREADS, lds, h->stream>>>((const T *)h->A + (size_t)p.col_off * h->npad, h->npad, (const T *)h->Wop,
                                                                               h->npad, h->Cx + p.col_off, h->mpad, (size_t)KP * h->mpad, p.stage_begin,
@@ -739,7 +788,7 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
     const int KP = 16 * NKQ;
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(KP);
-    hipFuncSetAttribute((const void *)xprod16_tn_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set_dyn_lds((const void *)xprod16_tn_kernel<NKQ>, lds, "xprod16_tn_kernel");
     xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
                                                                     (Cx ? Cx : h->Cx) + p.col_off, ldc, slab_stride ? slab_stride : (size_t)KP * ldc,
                                                                     p.stage_begin, p.stage_end, p.sps, h->scal_exp);
@@ -755,6 +804,7 @@ static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, 
     const double *Ym = (which == 1) ? h->W64 : h->H64;
     const int ldm = (which == 1) ? h->npad : h->mpad; // leading dimension of the master = padded contraction length
     const int plen_true = (which == 1) ? h->n : h->m;
+    h->y16_for = -1; // (Y16 is rewritten)
     if (!mb) {
         mb = h->maxbits;
         hipMemsetAsync(mb, 0, sizeof(unsigned), h->stream);
@@ -779,7 +829,7 @@ static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
 {
     dim3 grid(p.tiles_x, p.S);
     const int lds = 2 * XPROD16_ERR_BUF;
-    hipFuncSetAttribute((const void *)xprod16_err_kernel<NKQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set_dyn_lds((const void *)xprod16_err_kernel<NKQ>, lds, "xprod16_err_kernel");
     xprod16_err_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
                                                                      (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
                                                                      h->scal_exp + 2, h->n, h->m, h->partials);
@@ -818,7 +868,7 @@ static int ensure_AT(nnlm_handle *h)
     dim3 grid(h->npad / 64, h->mpad / 64);
     if (h->prec == NNLM_PREC_F64) transpose_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, (double *)h->AT, h->mpad);
     else transpose_kernel<float><<<grid, 256, 0, h->stream>>>((const float *)h->A, h->npad, (float *)h->AT, h->mpad);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     return NNLM_OK;
 }
 
@@ -827,7 +877,7 @@ static void launch_xprod_tn_rows(nnlm_handle *h, const T *Amat, int lda, const T
 {
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod_tn_lds_bytes(16 * NKQ);
-    hipFuncSetAttribute((const void *)xprod_tn_kernel<T, NKQ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set_dyn_lds((const void *)xprod_tn_kernel<T, NKQ, 0>, lds, "xprod_tn_kernel");
     xprod_tn_kernel<T, NKQ, 0><<<grid, XPROD_THREADS, lds, h->stream>>>(Amat + (size_t)p.col_off * lda, lda, Y, ldy, C + p.col_off, ldc, slab_stride,
                                                                          p.stage_begin, p.stage_end, p.sps);
 }
@@ -959,7 +1009,7 @@ static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 &
 template <int NT, int NB, bool M, bool S> static void launch_sweep_q_k(nnlm_handle *h, const SweepArgs &a, int nb)
 {
     const int lds = (int)sweepq_lds_bytes(16 * NT, NB, S); // x image + operand image (up to 75 KB at k = 64)
-    hipFuncSetAttribute((const void *)sweep_scd_q_kernel<NT, NB, M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set_dyn_lds((const void *)sweep_scd_q_kernel<NT, NB, M, S>, lds, "sweep_scd_q_kernel");
     sweep_scd_q_kernel<NT, NB, M, S><<<nb, SWEEPQ_THREADS, lds, h->stream>>>(a, h->sweepq_img);
 }
 template <int NT, int NB> static void launch_sweep_q_m(nnlm_handle *h, const SweepArgs &a, int nb)
@@ -1009,10 +1059,10 @@ static int launch_sweep_generic(nnlm_handle *h, int method, const SweepArgs &a, 
     if (lds > (size_t)160 * 1024) return fail(h, NNLM_ERR_UNSUPPORTED, "rank %d needs %zu bytes of LDS per workgroup (limit 160 KiB)", a.k, lds);
     const int nb = (ncols + 3) / 4;
     if (method == 1) {
-        hipFuncSetAttribute((const void *)sweep_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)sweep_generic_kernel<1>, (int)lds, "sweep_generic_kernel");
         sweep_generic_kernel<1><<<nb, 256, lds, h->stream>>>(a, g_stride, h->MW, g_in_lds ? 1 : 0);
     } else {
-        hipFuncSetAttribute((const void *)sweep_generic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)sweep_generic_kernel<2>, (int)lds, "sweep_generic_kernel");
         sweep_generic_kernel<2><<<nb, 256, lds, h->stream>>>(a, g_stride, h->MW, g_in_lds ? 1 : 0);
     }
     return NNLM_OK;
@@ -1043,10 +1093,10 @@ static void launch_kl64_m(int method, const Kl64Args &ka, hipStream_t s)
     if (nb <= 0) return;
     const size_t lds = kl64_lds_bytes(EPT2, C, ka.k);
     if (method == 3) {
-        hipFuncSetAttribute((const void *)kl_reg64_kernel<EPT2, C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)kl_reg64_kernel<EPT2, C, 3>, (int)lds, "kl_reg64_kernel");
         kl_reg64_kernel<EPT2, C, 3><<<nb, KL64_THREADS, lds, s>>>(ka);
     } else {
-        hipFuncSetAttribute((const void *)kl_reg64_kernel<EPT2, C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)kl_reg64_kernel<EPT2, C, 4>, (int)lds, "kl_reg64_kernel");
         kl_reg64_kernel<EPT2, C, 4><<<nb, KL64_THREADS, lds, s>>>(ka);
     }
 }
@@ -1074,10 +1124,10 @@ template <int EPT4, int C, bool ONEBUF = false>
 static void launch_kl_tile_m(int method, const KlTileArgs &ta, int nb, size_t lds, hipStream_t s)
 {
     if (method == 3) {
-        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 3, ONEBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)kl_tile_kernel<EPT4, C, 3, ONEBUF>, (int)lds, "kl_tile_kernel");
         kl_tile_kernel<EPT4, C, 3, ONEBUF><<<nb, KLT_THREADS, lds, s>>>(ta);
     } else {
-        hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, 4, ONEBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dyn_lds((const void *)kl_tile_kernel<EPT4, C, 4, ONEBUF>, (int)lds, "kl_tile_kernel");
         kl_tile_kernel<EPT4, C, 4, ONEBUF><<<nb, KLT_THREADS, lds, s>>>(ta);
     }
 }
@@ -1403,7 +1453,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         // starting state vectors y = Yt^T x of ALL columns as one GEMM, in the layout the solver reads: [column][contraction]
         const int k2 = round_up_i(h->k, 2);
         const int lds = 2 * k2 * ERRF_TILE * (int)sizeof(float);
-        hipFuncSetAttribute((const void *)wh_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        set_dyn_lds((const void *)wh_store_kernel, lds, "wh_store_kernel");
         // (multi-GPU: only the column tiles of this rank's shard -- its first column is a multiple of 256)
         const int ct0 = a.col0 / ERRF_TILE, ct1 = (a.ncols + ERRF_TILE - 1) / ERRF_TILE;
         const int ny = ct1 > ct0 ? ct1 - ct0 : 0;
@@ -1545,7 +1595,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         if (rcs != NNLM_OK) return rcs;
     }
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     if (h->sharded) {
         if (phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
         int rc = pack_gather_unpack(h, which, phase);
@@ -1723,7 +1773,8 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         // (multi-GPU: the unpack of the previous half-step left max|fixed factor| behind -- no absmax pass)
         const int solved_by = (which == 1) ? 0 : 1; // the half-step that solved this half-step's fixed factor
         unsigned *mb = (h->sharded && h->upk_max_for == solved_by) ? h->maxbits + 6 + solved_by : gmb;
-        prepare_factor16(h, which, mb);
+        // (dense SCD, column form: that unpack also wrote the split copy and its exponent -- the ranks' maxima travelled with the slabs)
+        if (!(h->sharded && mb && h->y16_for == solved_by && !h->fuse_err)) prepare_factor16(h, which, mb);
         h->fixed_maxw = mb ? mb : h->maxbits;
     }
     if (p.tiles_x > 0) {
@@ -1748,6 +1799,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         slab_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->Cx, p.S, cnt, h->red + (size_t)h->KP * h->KP);
         if (phase == PH_A) return NNLM_OK; // test hooks: the caller performs the exchange
         if (h->comm) {
+            ProfScope ps(h, P_ALLREDUCE);
             ncclResult_t r = g_rccl.AllReduce(h->red, h->red, (size_t)h->KP * h->KP + cnt, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
             if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
         }
@@ -1757,28 +1809,38 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
 
 static int shard_unpack(nnlm_handle *h, int which)
 {
+    ProfScope ps(h, P_UNPACK);
     const int ncols = (which == 1) ? h->m : h->n;
     const ShardCols sc = shard_cols(h, ncols);
-    const size_t tot = (size_t)h->nranks * h->k * sc.cpr; // (the k meaningful rows of every rank's [KP][cpr] slab travel, not the padding)
     const int f64 = (h->prec == NNLM_PREC_F64) ? 1 : 0;
     unsigned *maxw = h->x16 ? h->maxbits + 6 + which : nullptr; // max|factor| for the next half-step's split copy (no absmax pass there)
-    if (maxw) HIPCHK(h, hipMemsetAsync(maxw, 0, sizeof(unsigned), h->stream));
+    // dense SCD in the column form (pack_tail = KP * KP Gram partial sums + the rank's max|x|): max|factor| is known before an entry is
+    // read, so the unpack writes the split-fp16 copy of the factor -- the fixed factor of the NEXT half-step -- and its exponent too
+    const bool tail_max = h->pack_tail != 0 && h->x16;
+    const size_t tail_max_off = tail_max ? (size_t)h->k * sc.cpr + (size_t)h->KP * h->KP : (size_t)-1;
+    uint32_t *y16 = (tail_max && !generic_rank(h)) ? h->Y16 : nullptr;
+    const int rows = y16 ? h->KP : h->k; // (the k meaningful rows of every rank's [KP][cpr] slab travel, not the padding; the split copy is zero padded)
+    const size_t tot = (size_t)h->nranks * rows * sc.cpr;
+    if (maxw && !tail_max) HIPCHK(h, hipMemsetAsync(maxw, 0, sizeof(unsigned), h->stream));
     h->upk_max_for = maxw ? which : -1;
     const size_t rank_stride = (size_t)h->k * sc.cpr + h->pack_tail;
     if (which == 1)
-        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols, h->H64,
-                                                                                   h->mpad, nullptr, 0, 0, f64, maxw, rank_stride);
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, rows, sc.cpr, h->k, ncols, h->H64,
+                                                                                   h->mpad, nullptr, 0, 0, f64, maxw, rank_stride, tail_max_off, y16,
+                                                                                   h->mpad, h->scal_exp + 1);
     else
-        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, h->k, sc.cpr, h->k, ncols,
+        shard_unpack_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, h->stream>>>(h->pack_all, h->nranks, rows, sc.cpr, h->k, ncols,
                                                                                    h->W64b[h->wcur ^ 1], h->npad, h->Wopb[h->wcur ^ 1],
-                                                                                   f64 ? 0 : 1, h->npad, f64, maxw, rank_stride);
+                                                                                   f64 ? 0 : 1, h->npad, f64, maxw, rank_stride, tail_max_off, y16,
+                                                                                   h->npad, h->scal_exp + 1);
+    h->y16_for = y16 ? which : -1;
     if (h->gshard_for == which) h->gshard_for = -1; // (that factor has just been rewritten)
     if (h->pack_tail) { // the Gram of the factor just gathered = the sum of the ranks' partial sums, in rank order
         const int cnt = h->KP * h->KP;
         shard_gram_sum_kernel<<<(cnt + 255) / 256, 256, 0, h->stream>>>(h->pack_all, h->nranks, rank_stride, (size_t)h->k * sc.cpr, cnt, h->Graw);
         h->gshard_for = which;
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     return NNLM_OK;
 }
 
@@ -1796,8 +1858,11 @@ static int pack_prepare(nnlm_handle *h, int ncols, struct ShardCols *out, size_t
         HIPCHK(h, hipMalloc(&h->pack_send, need * 8));
         HIPCHK(h, hipMalloc(&h->pack_all, need * h->nranks * 8));
         h->pack_elems = need * h->nranks;
-    }
-    HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+    } else if (sc.col1 <= sc.col0) // a rank without columns sends zeros (nothing below writes its slab or its tail)
+        HIPCHK(h, hipMemsetAsync(h->pack_send, 0, need * 8, h->stream));
+    // (otherwise no memset per half-step: the solvers write every live entry -- rows < k of the rank's columns --, the tail is written
+    //  whole, and the unpack reads nothing else)
     *out = sc;
     return NNLM_OK;
 }
@@ -1807,6 +1872,7 @@ static int pack_gather_unpack(nnlm_handle *h, int which, int phase)
     const int ncols = (which == 1) ? h->m : h->n;
     const ShardCols sc = shard_cols(h, ncols);
     if (h->comm) {
+        ProfScope ps(h, P_ALLGATHER);
         ncclResult_t r = g_rccl.AllGather(h->pack_send, h->pack_all, (size_t)h->k * sc.cpr + h->pack_tail, ncclDouble, (ncclComm_t)h->comm,
                                           h->stream); // rows 0 .. k-1 (+ the Gram partial sums behind them)
         if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
@@ -1823,7 +1889,8 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
 {
     const int ncols = (which == 1) ? h->m : h->n;
     // dense SCD in the column form: the Gram partial sums of this rank's columns travel with its slab (shard_gram_sum_kernel)
-    h->pack_tail = (h->sharded && colshard && method == 1 && !h->any_missing && !generic_rank(h)) ? (size_t)h->KP * h->KP : 0;
+    // (+ one double: the rank's max|x|, so that the unpack can write the split-fp16 copy of the factor as well)
+    h->pack_tail = (h->sharded && colshard && method == 1 && !h->any_missing && !generic_rank(h)) ? (size_t)h->KP * h->KP + 1 : 0;
     if (phase != PH_C) {
         ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
         SweepArgs a;
@@ -1887,6 +1954,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                     HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)((big + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1) * h->KP * h->KP * 8));
                 }
                 a.gram_slabs = h->sg_slabs; // (one slab per workgroup of sweep_scd_q_kernel; folded behind the packed slab below)
+                a.maxbits = h->x16 ? h->maxbits + 8 : nullptr; // (the sweep's atomicMax; handed to the tail and cleared by gram_fold_tail_kernel)
             }
         }
         if (h->any_missing) {
@@ -1907,7 +1975,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             if (rcs != NNLM_OK) return rcs;
             if (h->sharded && h->pack_tail) {
                 const int nsl = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
-                gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, nsl, h->KP, h->pack_send + (size_t)h->k * a.ldo);
+                gram_fold_tail_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, nsl, h->KP, h->pack_send + (size_t)h->k * a.ldo, h->maxbits + 8);
             }
             if (sg) { // the next half-step finds max and Gram partial sums of this factor
                 h->sg_nslabs = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
@@ -1916,7 +1984,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                 h->sg_other = h->sg_prev; // the word this sweep did not touch
             }
         }
-        HIPCHK(h, hipGetLastError());
+        LAUNCHCHK(h);
         if (h->sharded && phase == PH_B) return NNLM_OK; // test hooks: the caller gathers the slabs
     }
     if (h->sharded) {
@@ -1972,7 +2040,8 @@ extern "C" int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const doub
 {
     if (!h || !reg || (which != 0 && which != 1) || phase < PH_A || phase > PH_C) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: bad arguments");
     if (!h->sharded) return fail(h, NNLM_ERR_ARG, "nnlm_debug_phase: handle is not sharded (call nnlm_comm_init first)");
-    if (phase != PH_C) h->upk_max_for = -1; // (test hooks may have rewritten the factors since the last unpack: take the absmax pass)
+    // (nothing is reset here: nnlm_set_factors -- the only other writer of the factors -- invalidates what the last unpack left behind,
+    //  so virtual ranks take the production path: cached Gram, max|factor| and split copy from the previous half-step's unpack)
     return half_step(h, which, reg, inner_max_iter, inner_rel_tol, method, false, false, phase);
 }
 
@@ -2043,7 +2112,7 @@ extern "C" int nnlm_sync(nnlm_handle *h)
     if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_sync: handle is NULL");
     HIPCHK(h, hipSetDevice(h->device));
     sync_all(h);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     return NNLM_OK;
 }
 
@@ -2085,11 +2154,11 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
             nb = (size_t)nit * nchunks;
             const int lds = errors64_lds_bytes(k4);
             if (miss) {
-                hipFuncSetAttribute((const void *)errors64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                set_dyn_lds((const void *)errors64_kernel<true>, lds, "errors64_kernel");
                 errors64_kernel<true><<<(unsigned)nb, ERR64_THREADS, lds, st>>>((const double *)h->A, h->npad, miss, h->W64, h->npad, h->H64, h->mpad, h->n,
                                                                                 h->m, k4, h->partials, jt0, jcnt, chunk, nit);
             } else {
-                hipFuncSetAttribute((const void *)errors64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                set_dyn_lds((const void *)errors64_kernel<false>, lds, "errors64_kernel");
                 errors64_kernel<false><<<(unsigned)nb, ERR64_THREADS, lds, st>>>((const double *)h->A, h->npad, nullptr, h->W64, h->npad, h->H64, h->mpad,
                                                                                  h->n, h->m, k4, h->partials, jt0, jcnt, chunk, nit);
             }
@@ -2110,11 +2179,11 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
             const size_t cnt = (size_t)h->KP * h->mpad;
             factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(h->H64, cnt, h->Hkq);
             if (h->any_missing) {
-                hipFuncSetAttribute((const void *)errors_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                set_dyn_lds((const void *)errors_f32_kernel<true>, lds, "errors_f32_kernel");
                 errors_f32_kernel<true><<<grid, 256, lds, st>>>((const float *)h->A, h->npad, h->missT, h->mpad / 32, (const float *)h->Wop, h->npad, h->Hkq,
                                                                 h->mpad, h->n, h->m, k2, h->partials, jt0, nx);
             } else {
-                hipFuncSetAttribute((const void *)errors_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                set_dyn_lds((const void *)errors_f32_kernel<false>, lds, "errors_f32_kernel");
                 errors_f32_kernel<false><<<grid, 256, lds, st>>>((const float *)h->A, h->npad, nullptr, 0, (const float *)h->Wop, h->npad, h->Hkq, h->mpad,
                                                                  h->n, h->m, k2, h->partials, jt0, nx);
             }
@@ -2146,7 +2215,7 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
         HIPCHK(h, hipMemsetAsync(h->sweeps + h->sw_active, 0, sizeof(unsigned long long), st));
     }
     HIPCHK(h, hipEventRecord(h->ev_err, st));
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     return NNLM_OK;
 }
 
@@ -2236,8 +2305,7 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     }
     h->rank = rank;
     h->nranks = nranks;
-    h->upk_max_for = -1; // (the cached max|factor| of an unpack belongs to the previous communicator's exchange)
-    h->gshard_for = -1;
+    invalidate_factor_caches(h); // (what an unpack left behind belongs to the previous communicator's exchange)
     h->pack_tail = 0;
     h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
     {
@@ -2486,7 +2554,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         cb_print(cb, "%10s | %10s | %10s | %10s | %10s\n\n", "Iteration", "MSE", "MKL", "Target", "Rel. Err.");
     }
     sync_all(h);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHCHK(h);
     *n_trace = (int)i_e;
     *n_iteration = i;
     *warned = (show_warning && rel_err > rel_tol) ? 1 : 0; // src/nnmf.cpp:208
@@ -2524,7 +2592,7 @@ extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const doub
         for (int i = 0; i < n; i++)
             for (unsigned q = 0; q < k; q++) {
                 double v = draw() * 0.01;
-                if (Wm && Wm[(size_t)q * n + i] > 0) v = 0.0;
+                if (Wm && Wm[(size_t)q * n + i] != 0) v = 0.0; // (Wm > 0 on the reference's unsigned matrix: any non-zero, NA_LOGICAL included)
                 Wi[(size_t)q * n + i] = v;
             }
         W_init = Wi.data();
@@ -2533,7 +2601,7 @@ extern "C" int nnlm_c_nnmf(const double *A, int n, int m, unsigned k, const doub
         Hi.resize((size_t)k * m);
         for (size_t e = 0; e < (size_t)k * m; e++) {
             double v = draw() * 0.01;
-            if (Hm && Hm[e] > 0) v = 0.0;
+            if (Hm && Hm[e] != 0) v = 0.0;
             Hi[e] = v;
         }
         H_init = Hi.data();

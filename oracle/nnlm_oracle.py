@@ -36,7 +36,7 @@ def scd_ls_update(Hj, WtW, mu, mask, max_iter, rel_tol):
     while t < max_iter and rel_err > rel_tol:
         rel_err = 0.0
         for q in range(k):
-            if is_masked and mask[q] > 0:
+            if is_masked and mask[q] != 0:  # `mask(k) > 0` on an unsigned matrix
                 continue
             tmp = Hj[q] - mu[q] / WtW[q, q]
             if tmp < 0:
@@ -62,7 +62,7 @@ def lee_ls_update(Hj, WtW, WtAj, beta3, mask, max_iter, rel_tol):
     while t < max_iter and rel_err > rel_tol:
         rel_err = 0.0
         for q in range(k):
-            if is_masked and mask[q] > 0:
+            if is_masked and mask[q] != 0:  # `mask(k) > 0` on an unsigned matrix
                 continue
             tmp = float(np.dot(WtW[:, q], Hj)) + beta3
             tmp = WtAj[q] / (tmp + TINY_NUM)
@@ -85,7 +85,7 @@ def scd_kl_update(Hj, Wt, Aj, sumW, mask, beta, max_iter, rel_tol):
     while t < max_iter and rel_err > rel_tol:
         rel_err = 0.0
         for q in range(k):
-            if is_masked and mask[q] > 0:
+            if is_masked and mask[q] != 0:  # `mask(k) > 0` on an unsigned matrix
                 continue
             mu = Wt[q, :] / (Ajt + TINY_NUM)
             a = float(np.dot(Aj, mu * mu))
@@ -117,7 +117,7 @@ def lee_kl_update(Hj, Wt, Aj, sumW, mask, beta, max_iter, rel_tol):
     while t < max_iter and rel_err > rel_tol:
         rel_err = 0.0
         for q in range(k):
-            if is_masked and mask[q] > 0:
+            if is_masked and mask[q] != 0:  # `mask(k) > 0` on an unsigned matrix
                 continue
             tmp = float(np.dot(Wt[q, :], Aj / (wh + TINY_NUM)))
             tmp /= (sumW[q] + beta[0] * Hj[q] + beta[1] * (sumHj - Hj[q]) + beta[2])
@@ -308,14 +308,14 @@ def c_nnmf(A, k, W, H, Wm, Hm, alpha, beta, max_iter, rel_tol, n_threads, verbos
         rng = rng or np.random.default_rng(0)
         Wt = rng.random((n, k)).T.copy() * 0.01  # column-major draw order of a k x n matrix
         if Wmt is not None:
-            Wt[Wmt > 0] = 0.0
+            Wt[Wmt != 0] = 0.0
     else:
         Wt = np.array(np.asarray(W, dtype=np.float64).T, order="C", copy=True)
     if H is None or np.size(H) == 0:
         rng = rng or np.random.default_rng(0)
         Hc = rng.random((m, k)).T.copy() * 0.01
         if Hmm is not None:
-            Hc[Hmm > 0] = 0.0
+            Hc[Hmm != 0] = 0.0
     else:
         Hc = np.array(H, dtype=np.float64, copy=True)
 

@@ -45,7 +45,7 @@ int ref_scd_ls_update(double *Hj, const double *WtW, double *mu, const int *mask
     for (; t < max_iter && rel_err > rel_tol; t++) {
         rel_err = 0;
         for (int q = 0; q < k; q++) {
-            if (mask && mask[q] > 0) continue;
+            if (mask && mask[q] != 0) continue; /* `mask(k) > 0` on the reference's UNSIGNED matrix: any non-zero (R's NA_LOGICAL = INT_MIN converts to a huge uword) */
             double tmp = Hj[q] - mu[q] / WtW[q + (size_t)q * k];
             if (tmp < 0) tmp = 0;
             if (tmp != Hj[q]) {
@@ -71,7 +71,7 @@ int ref_lee_ls_update(double *Hj, const double *WtW, const double *WtAj, double 
     for (; t < max_iter && rel_err > rel_tol; t++) {
         rel_err = 0;
         for (int q = 0; q < k; q++) {
-            if (mask && mask[q] > 0) continue;
+            if (mask && mask[q] != 0) continue; /* `mask(k) > 0` on the reference's UNSIGNED matrix: any non-zero (R's NA_LOGICAL = INT_MIN converts to a huge uword) */
             const double *col = WtW + (size_t)q * k;
             double tmp = 0;
             for (int r = 0; r < k; r++) tmp += col[r] * Hj[r];
@@ -104,7 +104,7 @@ int ref_scd_kl_update(double *Hj, const double *Wt, int ldw, const double *Aj, i
     for (; t < max_iter && rel_err > rel_tol; t++) {
         rel_err = 0;
         for (int q = 0; q < k; q++) {
-            if (mask && mask[q] > 0) continue;
+            if (mask && mask[q] != 0) continue; /* `mask(k) > 0` on the reference's UNSIGNED matrix: any non-zero (R's NA_LOGICAL = INT_MIN converts to a huge uword) */
             double a = 0, b = 0;
             for (int i = 0; i < p; i++) {
                 double mu = Wt[q + (size_t)i * ldw] / (Ajt[i] + TINY_NUM);
@@ -147,7 +147,7 @@ int ref_lee_kl_update(double *Hj, const double *Wt, int ldw, const double *Aj, i
     for (; t < max_iter && rel_err > rel_tol; t++) {
         rel_err = 0;
         for (int q = 0; q < k; q++) {
-            if (mask && mask[q] > 0) continue;
+            if (mask && mask[q] != 0) continue; /* `mask(k) > 0` on the reference's UNSIGNED matrix: any non-zero (R's NA_LOGICAL = INT_MIN converts to a huge uword) */
             double tmp = 0;
             for (int i = 0; i < p; i++) tmp += Wt[q + (size_t)i * ldw] * (Aj[i] / (wh[i] + TINY_NUM));
             tmp /= (sumW[q] + beta[0] * Hj[q] + beta[1] * (sumHj - Hj[q]) + beta[2]);
@@ -471,14 +471,14 @@ int ref_c_nnmf(const double *A, int n, int m, unsigned k_, double *W, int W_give
         for (size_t e = 0; e < (size_t)k * n; e++) Wt[e] = DRAW() * 0.01;
         if (Wmt)
             for (size_t e = 0; e < (size_t)k * n; e++)
-                if (Wmt[e] > 0) Wt[e] = 0.0;
+                if (Wmt[e] != 0) Wt[e] = 0.0; /* find(Wm > 0) on arma::umat */
     } else
         transpose(W, n, k, Wt, n_threads);
     if (!H_given) { /* :92-98 */
         for (size_t e = 0; e < (size_t)k * m; e++) H[e] = DRAW() * 0.01;
         if (Hm)
             for (size_t e = 0; e < (size_t)k * m; e++)
-                if (Hm[e] > 0) H[e] = 0.0;
+                if (Hm[e] != 0) H[e] = 0.0;
     }
 #undef DRAW
 

@@ -21,10 +21,27 @@
 
 #include "nnlm_mi355x.h"
 
-/* Re-raises a pending user interrupt after the handle has been released.  Declared in Rinterface.h (the Unix embedding
- * header), not in Rinternals.h: declared here so that no platform header is needed and no implicit declaration is left
- * for compilers that reject them. */
-extern void Rf_onintr(void);
+/* Re-raises the user interrupt the library reported (NNLM_ERR_INTERRUPT) -- after the device handle has been released, so the jump
+ * crosses no C++ frame.  The poll inside the library runs R_CheckUserInterrupt() under R_ToplevelExec(), which CONSUMES the pending
+ * interrupt; R's own way of raising it again, Rf_onintr() (what Rcpp's END_RCPP calls), is not part of the API `R CMD check` accepts.
+ * This does what onintr() does through API entry points only: a condition of class c("interrupt", "condition") is signalled to the
+ * handler stack (tryCatch(interrupt = ) unwinds to its handler, withCallingHandlers() sees it) and, if nothing took it, control
+ * returns to top level through the "abort" restart. */
+static void raise_interrupt(void)
+{
+    SEXP cls = PROTECT(Rf_allocVector(STRSXP, 2));
+    SEXP cond = PROTECT(Rf_allocVector(VECSXP, 0));
+    SEXP call, arg;
+    SET_STRING_ELT(cls, 0, Rf_mkChar("interrupt"));
+    SET_STRING_ELT(cls, 1, Rf_mkChar("condition"));
+    Rf_setAttrib(cond, R_ClassSymbol, cls);
+    call = PROTECT(Rf_lang2(Rf_install("signalCondition"), cond));
+    Rf_eval(call, R_BaseEnv);
+    arg = PROTECT(Rf_mkString("abort"));
+    call = PROTECT(Rf_lang2(Rf_install("invokeRestart"), arg));
+    Rf_eval(call, R_BaseEnv); /* does not return */
+    UNPROTECT(5);
+}
 
 /* ---- callbacks = the R API points the reference touches (include/nnlm_mi355x.h nnlm_callbacks) ---------------- */
 static void chk_intr_body(void *dummy) { (void)dummy; R_CheckUserInterrupt(); }
@@ -89,7 +106,7 @@ SEXP _NNLM_c_nnmf(SEXP ASEXP, SEXP kSEXP, SEXP WSEXP, SEXP HSEXP, SEXP WmSEXP, S
                      Rf_asReal(inner_rel_tolSEXP), Rf_asInteger(methodSEXP), trace, REAL(W), REAL(H), REAL(mse), REAL(mkl),
                      REAL(terr), REAL(ep), &n_trace, &n_iteration, &warned, &k_callbacks);
     PutRNGstate();
-    if (rc == NNLM_ERR_INTERRUPT) { UNPROTECT(7); Rf_onintr(); return R_NilValue; }
+    if (rc == NNLM_ERR_INTERRUPT) { UNPROTECT(7); raise_interrupt(); return R_NilValue; }
     if (rc != NNLM_OK) { UNPROTECT(7); Rf_error("%s", nnlm_last_error(NULL)); } /* BEGIN_RCPP/END_RCPP: C++ exception -> R error */
 
     SET_VECTOR_ELT(out, 0, W);

@@ -16,7 +16,7 @@ typedef enum { FALSE = 0, TRUE } Rboolean;
 #define STRSXP 16
 #define VECSXP 19
 #define CHARSXP 9
-extern SEXP R_NilValue, R_NamesSymbol;
+extern SEXP R_NilValue, R_NamesSymbol, R_ClassSymbol, R_BaseEnv;
 SEXP Rf_protect(SEXP);
 void Rf_unprotect(int);
 #define PROTECT(s) Rf_protect(s)
@@ -24,6 +24,12 @@ void Rf_unprotect(int);
 SEXP Rf_allocVector(unsigned int type, R_xlen_t n);
 SEXP Rf_allocMatrix(unsigned int type, int nrow, int ncol);
 SEXP Rf_mkChar(const char *);
+SEXP Rf_mkString(const char *);
+SEXP Rf_install(const char *);
+SEXP Rf_lang2(SEXP, SEXP);
+SEXP Rf_eval(SEXP, SEXP);
+#define SYMSXP 1
+#define LANGSXP 6
 void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v);
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
 SEXP Rf_setAttrib(SEXP vec, SEXP name, SEXP val);

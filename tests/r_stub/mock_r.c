@@ -18,9 +18,11 @@ struct SEXPREC {
     int nrow, ncol;
     void *data;   /* double* / int* / SEXP* / char* */
     SEXP names;
+    SEXP klass;   /* class attribute (STRSXP) or NULL */
 };
-static struct SEXPREC nil_rec = {0, 0, 0, 0, NULL, NULL}, names_rec = {0, 0, 0, 0, NULL, NULL};
-SEXP R_NilValue = &nil_rec, R_NamesSymbol = &names_rec;
+static struct SEXPREC nil_rec = {0, 0, 0, 0, NULL, NULL, NULL}, names_rec = {0, 0, 0, 0, NULL, NULL, NULL}, class_rec = {0, 0, 0, 0, NULL, NULL, NULL},
+                      base_rec = {0, 0, 0, 0, NULL, NULL, NULL};
+SEXP R_NilValue = &nil_rec, R_NamesSymbol = &names_rec, R_ClassSymbol = &class_rec, R_BaseEnv = &base_rec;
 
 static jmp_buf mock_jmp;
 static int mock_jmp_armed = 0, mock_protect_depth = 0, mock_interrupt_after = -1, mock_interrupt_polls = 0, mock_rng_depth = 0;
@@ -53,7 +55,10 @@ SEXP Rf_mkChar(const char *c)
 }
 void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP *)x->data)[i] = v; }
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP *)x->data)[i] = v; return v; }
-SEXP Rf_setAttrib(SEXP vec, SEXP name, SEXP val) { if (name == R_NamesSymbol) vec->names = val; return val; }
+SEXP Rf_setAttrib(SEXP vec, SEXP name, SEXP val) { if (name == R_NamesSymbol) vec->names = val; else if (name == R_ClassSymbol) vec->klass = val; return val; }
+SEXP Rf_mkString(const char *c) { SEXP s = Rf_allocVector(STRSXP, 1); SET_STRING_ELT(s, 0, Rf_mkChar(c)); return s; }
+SEXP Rf_install(const char *c) { SEXP s = Rf_mkChar(c); s->type = SYMSXP; return s; }
+SEXP Rf_lang2(SEXP fn, SEXP arg) { SEXP s = Rf_allocVector(VECSXP, 2); s->type = LANGSXP; ((SEXP *)s->data)[0] = fn; ((SEXP *)s->data)[1] = arg; return s; }
 R_xlen_t XLENGTH(SEXP x) { return x->len; }
 int *LOGICAL(SEXP x) { return (int *)x->data; }
 double *REAL(SEXP x) { return (double *)x->data; }
@@ -81,7 +86,35 @@ void Rf_warning(const char *fmt, ...)
     va_list ap; va_start(ap, fmt); vsnprintf(mock_warning_text, sizeof mock_warning_text, fmt, ap); va_end(ap);
     mock_warnings++;
 }
-void Rf_onintr(void) { mock_onintr++; if (mock_jmp_armed) { snprintf(mock_error, sizeof mock_error, "interrupt"); longjmp(mock_jmp, 2); } }
+/* The two calls r_glue.c evaluates to raise an interrupt: signalCondition(<condition of class "interrupt">) finds no handler in this
+ * mock and returns; invokeRestart("abort") jumps to top level. */
+static int mock_interrupt_signalled = 0;
+SEXP Rf_eval(SEXP call, SEXP env)
+{
+    (void)env;
+    if (call->type != LANGSXP) return call;
+    {
+        const char *fn = (const char *)((SEXP *)call->data)[0]->data;
+        SEXP arg = ((SEXP *)call->data)[1];
+        if (strcmp(fn, "signalCondition") == 0) {
+            int is_intr = 0;
+            if (arg->klass)
+                for (R_xlen_t i = 0; i < arg->klass->len; i++)
+                    if (strcmp((const char *)((SEXP *)arg->klass->data)[i]->data, "interrupt") == 0) is_intr = 1;
+            if (is_intr) mock_interrupt_signalled = 1;
+            return R_NilValue;
+        }
+        if (strcmp(fn, "invokeRestart") == 0 && strcmp((const char *)((SEXP *)arg->data)[0]->data, "abort") == 0) {
+            if (mock_interrupt_signalled) mock_onintr++;
+            mock_interrupt_signalled = 0;
+            if (mock_jmp_armed) { snprintf(mock_error, sizeof mock_error, "interrupt"); longjmp(mock_jmp, 2); }
+            return R_NilValue;
+        }
+    }
+    snprintf(mock_error, sizeof mock_error, "mock R cannot evaluate this call");
+    if (mock_jmp_armed) longjmp(mock_jmp, 1);
+    abort();
+}
 void Rprintf(const char *fmt, ...)
 {
     const size_t used = strlen(mock_output);
@@ -159,7 +192,7 @@ int mock_registered_arity(int i) { return mock_calls[i].numArgs; }
 void R_init_NNLM(DllInfo *dll);
 void mock_load_package(void) { R_init_NNLM(NULL); }
 
-/* .Call through the registration table, guarded like R's top level: returns NULL after Rf_error / Rf_onintr */
+/* .Call through the registration table, guarded like R's top level: returns NULL after Rf_error / an interrupt raised through the "abort" restart */
 typedef SEXP (*call9_t)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*call17_t)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 SEXP mock_dotcall(const char *name, int nargs, SEXP *a)

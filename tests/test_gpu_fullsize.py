@@ -78,6 +78,17 @@ def test_config2_f32_twenty_iterations_drift_and_fused_error_traces():
     assert np.all(W >= 0) and np.all(H >= 0)
 
 
+_ORACLE_CACHE = {}
+
+
+def oracle_config2_two_iterations(A, W0, H0):
+    """ref.c_nnmf on BASELINE configs[1], two outer iterations, trace 1 (computed once per session: several tests compare with it)."""
+    if "c2x2" not in _ORACLE_CACHE:
+        z = [0.0, 0.0, 0.0]
+        _ORACLE_CACHE["c2x2"] = ref.c_nnmf(A, K, W0, H0, None, None, z, z, 2, -1.0, 0, 0, False, 50, 1e-9, 1, 1)
+    return _ORACLE_CACHE["c2x2"]
+
+
 def test_config2_f64_two_iterations_strict():
     """The strict fp64 mode at full size: two iterations, integer outputs exact."""
     A, W0, H0 = inputs()
@@ -87,7 +98,7 @@ def test_config2_f64_two_iterations_strict():
         h.set_factors(K, W0, H0)
         r = h.run(z, z, 2, -1.0, 0, False, 50, 1e-9, 1, 1)
         W, H = h.get_factors()
-    o = ref.c_nnmf(A, K, W0, H0, None, None, z, z, 2, -1.0, 0, 0, False, 50, 1e-9, 1, 1)
+    o = oracle_config2_two_iterations(A, W0, H0)
     ew, eh = relF(W, o["W"]), relF(H, o["H"])
     report("config2_f64_2_iterations", relF_W=ew, relF_H=eh,
            max_rel_mse_trace=float(np.max(np.abs(r["mse_error"] - o["mse_error"]) / o["mse_error"])))
@@ -278,3 +289,108 @@ def test_config2_lee_ls_full_size_one_iteration(pname, prec, tol):
         assert sweeps / (N + M) == float(o["average_epoch"][-1])  # sweep counts exact in the reference's arithmetic
     assert np.all(W1 >= 0) and np.all(H1 >= 0)
 
+
+
+# ---- BASELINE configs[3]: the 8-GPU configuration at its size, through 8 virtual ranks on one device ------------------------------
+def _virtual_rank_iterations(A, W0, H0, prec, world, iters, reg, inner, method, reduce_form):
+    """`iters` outer iterations of the sharded half-steps on `world` virtual ranks (nnlm_comm_init(NULL, r, world)): every rank runs
+    the product's own phases (nnlm_debug_phase), the host stands in for ncclAllReduce / ncclAllGather (nnlm_debug_exchange).
+    Returns per-rank factors, the summed sweep counter and the summed error sums."""
+    hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
+    try:
+        for rk, h in enumerate(hs):
+            h.comm_init(None, rk, world)
+            h.set_matrix(A)
+            h.set_factors(K, W0, H0)
+        for _ in range(iters):
+            for which in (0, 1):
+                for h in hs:
+                    h.debug_phase(which, 1, reg, inner, 1e-9, method)
+                if reduce_form:
+                    _lib.debug_exchange(hs, which, 1)
+                for h in hs:
+                    h.debug_phase(which, 2, reg, inner, 1e-9, method)
+                _lib.debug_exchange(hs, which, 2)
+                for h in hs:
+                    h.debug_phase(which, 3, reg, inner, 1e-9, method)
+        res = [h.get_factors() for h in hs]
+        sweeps = sum(h.take_sweeps() for h in hs)
+        mse = sum(h.errors()[0] for h in hs)  # (each rank reduces its share of the j-tiles)
+    finally:
+        for h in hs:
+            h.close()
+    return res, sweeps, mse
+
+
+@pytest.mark.parametrize("form", ["cols", "reduce"])
+@pytest.mark.parametrize("pname,prec", [("f32", _lib.PREC_F32), ("f64", _lib.PREC_F64)])
+def test_config4_full_size_eight_virtual_ranks(monkeypatch, pname, prec, form):
+    """BASELINE configs[3] -- nnmf(A, k=50) MSE+SCD sharded across 8 GPUs -- at 20000 x 10000 through EIGHT virtual ranks on one
+    device, both forms of the dense half-step (`cols`: column shards + one all-gather, the default; `reduce`: north_star's
+    contraction shards + one all-reduce of [G | C] + all-gather), both arithmetic modes, two outer iterations of 50 sweeps: split
+    plans, cpr = 2560 / 1280 with the last rank's short slab (2080 / 1040 columns), the Gram that travels with the factor,
+    shard_unpack at 313 / 157 workgroups per rank.  All ranks must end bit-identical, equal to the single-handle run up to the
+    summation order of the split, and equal to the oracle's c_nnmf; sweep counts exact in the strict mode."""
+    if form == "reduce":
+        monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
+    else:
+        monkeypatch.delenv("NNLM_SHARD_DENSE", raising=False)
+    A, W0, H0 = inputs()
+    z = [0.0, 0.0, 0.0]
+    with nnlm_amd.Handle(0, prec) as h1:
+        h1.set_matrix(A)
+        h1.set_factors(K, W0, H0)
+        h1.iterate(2, z, z, 50, 1e-9, 1)
+        W_one, H_one = h1.get_factors()
+        sw_one = h1.take_sweeps()
+        mse_one = h1.errors()[0]
+    res, sweeps, mse = _virtual_rank_iterations(A, W0, H0, prec, 8, 2, z, 50, 1, form == "reduce")
+    for W, H in res[1:]:
+        assert np.array_equal(W, res[0][0]) and np.array_equal(H, res[0][1])
+    W8, H8 = res[0]
+    o = oracle_config2_two_iterations(A, W0, H0)
+    ew1, eh1 = relF(W8, W_one), relF(H8, H_one)
+    ewo, eho = relF(W8, o["W"]), relF(H8, o["H"])
+    sw_or = int(round(float(np.sum(o["average_epoch"])) * (N + M)))
+    report(f"config4_8_virtual_ranks_{form}_{pname}", relF_W_vs_one_gpu=ew1, relF_H_vs_one_gpu=eh1, relF_W_vs_oracle=ewo, relF_H_vs_oracle=eho,
+           sweeps=sweeps, sweeps_one_gpu=sw_one, sweeps_oracle=sw_or, rel_mse_vs_one_gpu=abs(mse - mse_one) / mse_one,
+           rel_mse_vs_oracle=abs(mse - o["mse_error"][-1]) / o["mse_error"][-1])
+    t1 = 1e-10 if pname == "f64" else 2e-5
+    assert ew1 < t1 and eh1 < t1, (ew1, eh1)
+    to = 1e-9 if pname == "f64" else 1e-4
+    assert ewo < to and eho < to, (ewo, eho)
+    if pname == "f64":
+        assert sweeps == sw_one == sw_or  # per-column sweep counts, summed over ranks: exact
+    else:
+        assert abs(sweeps - sw_one) <= 2 + sw_one // 1000
+    assert abs(mse - mse_one) < (1e-9 if pname == "f64" else 1e-5) * mse_one
+    assert abs(mse - o["mse_error"][-1]) < (1e-9 if pname == "f64" else 1e-5) * o["mse_error"][-1]
+
+
+@pytest.mark.parametrize("name,method,na", [("config3_lee_mkl", 4, False), ("config5_na_reg", 1, True)])
+def test_configs_3_and_5_full_size_eight_virtual_ranks(name, method, na):
+    """BASELINE configs[2] (KL + Lee) and configs[4] (10 % NA + L1/L2) column-sharded over 8 virtual ranks at full size (F32 mode, one
+    outer iteration): per-rank state vectors / per-column Grams on a column range, packed slabs, all-gather, unpack.  Every rank
+    ends bit-identical and equal to the single-handle run (which the tests above hold against the oracle at this size)."""
+    A, W0, H0 = inputs()
+    if na:
+        A = A.copy()
+        A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+    reg = [0.01, 0.0, 0.01] if na else [0.0, 0.0, 0.0]
+    inner = 50 if method < 3 else 1
+    with nnlm_amd.Handle(0, _lib.PREC_F32) as h1:
+        h1.set_matrix(A)
+        h1.set_factors(K, W0, H0)
+        h1.iterate(1, reg, reg, inner, 1e-9, method)
+        W_one, H_one = h1.get_factors()
+        sw_one = h1.take_sweeps()
+        mse_one = h1.errors()[0]
+    res, sweeps, mse = _virtual_rank_iterations(A, W0, H0, _lib.PREC_F32, 8, 1, reg, inner, method, False)
+    for W, H in res[1:]:
+        assert np.array_equal(W, res[0][0]) and np.array_equal(H, res[0][1])
+    ew, eh = relF(res[0][0], W_one), relF(res[0][1], H_one)
+    report(f"{name}_8_virtual_ranks_f32", relF_W_vs_one_gpu=ew, relF_H_vs_one_gpu=eh, sweeps=sweeps, sweeps_one_gpu=sw_one,
+           rel_mse_vs_one_gpu=abs(mse - mse_one) / mse_one)
+    assert ew < 2e-5 and eh < 2e-5, (ew, eh)
+    assert abs(sweeps - sw_one) <= 2 + sw_one // 1000
+    assert abs(mse - mse_one) < 1e-5 * mse_one

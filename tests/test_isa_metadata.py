@@ -1,0 +1,69 @@
+"""The code object inside nnlm_amd/libnnlm_mi355x.so, read back without a GPU: every kernel instantiation's register and scratch
+figures from the AMDGPU metadata notes (llvm-objcopy -> clang-offload-bundler -> llvm-readelf --notes).
+
+A kernel with `private_segment_fixed_size > 0` spills registers to scratch memory; on gfx950 every reload is a `vmcnt(0)` drain of
+whatever the wavefront has in flight (DESIGN.md section 4.4 measured 0.27 -> 0.39 ms for a 24-byte spill).  VERDICT r3, item 5a: no
+instantiation may use scratch -- the list below names the ones still allowed to, and may only shrink.
+`python tests/test_isa_metadata.py` prints the table kept under profiles/."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "nnlm_amd", "libnnlm_mi355x.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# instantiations still allowed to spill (bytes of scratch per lane at the time of writing); everything else must be at 0
+ALLOWED_SCRATCH = {
+    "kl_reg64_kernel<20, 1, 3>": 108,
+    "errors64_kernel<true>": 104,
+    "kl_tile_kernel<20, 1, 3, true>": 80,
+    "kl_reg64_kernel<10, 2, 3>": 52,
+    "kl_tile_kernel<20, 1, 4, true>": 32,
+}
+
+
+def kernel_table():
+    """[(demangled name, vgprs, agprs, sgprs, scratch bytes, vgpr spills, lds bytes)] of every kernel in the gfx950 code object."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, SO])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    rows = []
+    for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
+        blk = ".agpr_count" + blk
+        get = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))  # noqa: E731
+        rows.append((re.search(r"\.name:\s+(\S+)", blk).group(1), get("vgpr_count"), get("agpr_count"), get("sgpr_count"),
+                     get("private_segment_fixed_size"), get("vgpr_spill_count"), get("group_segment_fixed_size")))
+    names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True, check=True).stdout.split("\n")
+    out = []
+    for r, nm in zip(rows, names):
+        nm = re.sub(r"^void ", "", nm)
+        nm = nm[:nm.index("(")] if "(" in nm else nm
+        out.append((nm,) + r[1:])
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(SO) or not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="needs the built library and ROCm's LLVM tools")
+def test_no_kernel_instantiation_uses_scratch_beyond_the_allowed_list():
+    tab = kernel_table()
+    assert len(tab) > 200  # (the whole library: ~285 instantiations)
+    bad = {nm: sc for nm, _, _, _, sc, _, _ in tab if sc > ALLOWED_SCRATCH.get(nm, 0)}
+    assert not bad, f"kernels spilling to scratch (bytes per lane): {bad}"
+    stale = [nm for nm in ALLOWED_SCRATCH if not any(t[0] == nm and t[4] > 0 for t in tab)]
+    assert not stale, f"no longer spilling -- remove from ALLOWED_SCRATCH: {stale}"
+
+
+if __name__ == "__main__":
+    tab = kernel_table()
+    print(f"# {len(tab)} kernel instantiations in {os.path.relpath(SO, ROOT)} (gfx950); scratch = private_segment_fixed_size, bytes per lane")
+    print(f"{'kernel':90s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch':>8s} {'spills':>7s} {'lds':>7s}")
+    for nm, vg, ag, sg, sc, sp, lds in sorted(tab, key=lambda t: (-t[4], t[0])):
+        print(f"{nm[:90]:90s} {vg:5d} {ag:5d} {sg:5d} {sc:8d} {sp:7d} {lds:7d}")
+    sys.exit(0)
