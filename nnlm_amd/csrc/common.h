@@ -51,6 +51,16 @@ __device__ static inline void glds16(const void *gsrc, void *lds_wave_base)
 #define NNLM_LN2F 0.69314718055994531f
 __device__ static inline float log2_native(float x) { return __builtin_amdgcn_logf(x); }
 
+// The reference's relative-change test  2|x_new - x| / (x_new + x + eps) > rel_tol  (src/base_algorithms.cpp:29-35), decided exactly
+// like its rounded quotient without a division on the common path: away from the boundary  2|d| > tol * s  is the same decision (both
+// roundings are below 2 ulp); inside a band of 1e-15 relative the IEEE quotient is formed and compared, as the reference does.
+__device__ static inline bool rel_change_exceeds(double d2, double s, double tol)
+{
+    const double rhs = tol * s;
+    if (__builtin_expect(fabs(d2 - rhs) <= 1e-15 * fabs(rhs), 0)) return d2 / s > tol;
+    return d2 > rhs;
+}
+
 __device__ static inline double wave_sum(double v)
 {
 #pragma unroll

@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
                         if (tmp != xq) { // uniform
                             const double d = tmp - xq;
                             v = __builtin_fma(d, g[c][e], v);
-                            // rel-change test without a division: rel only matters through "rel > rel_tol" (k_sweep.h)
-                            if (2 * fabs(d) > a.rel_tol * (tmp + xq + NNLM_TINY)) rel = 1.0 + fabs(a.rel_tol);
+                            // rel only matters through "rel > rel_tol": the quotient's decision, division only at the boundary (common.h)
+                            if (rel_change_exceeds(2 * fabs(d), tmp + xq + NNLM_TINY, a.rel_tol)) rel = 1.0 + fabs(a.rel_tol);
                             if (lane == q) x = tmp;
                         }
                     } else {
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void colsolve_strict_kernel(const SweepArgs a,
                             if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
                 }
             }
-            const bool big = 2 * fabs(x - xn) > a.rel_tol * (xn + x + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
+            const bool big = rel_change_exceeds(2 * fabs(x - xn), xn + x + NNLM_TINY, a.rel_tol); // src/base_algorithms.cpp:29-32, the quotient's decision
             x = xn;
             more = __ballot(big && lv) != 0ull || 0.0 > a.rel_tol;
         }

@@ -265,8 +265,8 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                         }
                         // rel-change test of src/base_algorithms.cpp:29-32 without the division:
                         //   2|d| / (tmp + x + eps) > tol   <=>   2|d| > tol * (tmp + x + eps)
-                        // (can differ from the rounded quotient's decision only when the two sides agree to ~2 ulp)
-                        const bool big = (EXP & 4) ? true : (2 * fabs(dd)) > tol * (tmp + xown + NNLM_TINY);
+                        // (the rounded quotient's decision: the division is formed only where the two sides agree to ~2 ulp, common.h)
+                        const bool big = (EXP & 4) ? true : rel_change_exceeds(2 * fabs(dd), tmp + xown + NNLM_TINY, tol);
                         flag |= (owner && big) ? 1 : 0;
                         xnew = (free_q && owner) ? tmp : xnew;
                         if (L == 1 && !(EXP & 2)) fetch(rowA, qn);

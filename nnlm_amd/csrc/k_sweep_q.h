@@ -333,9 +333,10 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
 #undef SQ_STAGE
 #undef SQ_IC
         const double d = c;
-        // rel-change test (src/base_algorithms.cpp:29-32), division-free: 2|d| > tol (x + d + x + eps)
+        // rel-change test (src/base_algorithms.cpp:29-32): fp32-operand mode division-free, 2|d| > tol (x + d + x + eps); strict mode the
+        // rounded quotient's decision (rel_change_exceeds, common.h: the division only where the two sides agree to ~2 ulp)
         if (TEST) {
-            if constexpr (STRICT) flag |= 2.0 * fabs(d) > tol * (tmpx + xb + NNLM_TINY); // (0 > .. when tmp == Hj(k): the reference's `continue`)
+            if constexpr (STRICT) flag |= rel_change_exceeds(2.0 * fabs(d), tmpx + xb + NNLM_TINY, tol); // (d = 0 when tmp == Hj(k): the reference's `continue`)
             else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
         }
         x[B] = STRICT ? tmpx : xb + d; // (strict: Hj(k) = tmp itself, src/base_algorithms.cpp:33)

@@ -787,6 +787,15 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
 {
     const int KP = 16 * NKQ;
     dim3 grid(p.tiles_x, p.S);
+    static const bool two_stage = getenv("NNLM_EXP_XPROD_NBUF2") != nullptr; // (round-4 probe, scripts/gpu_overlap_probe.py)
+    if (two_stage) {
+        const int lds2 = 2 * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB);
+        set_dyn_lds((const void *)xprod16_tn_kernel<NKQ, 0, 2>, lds2, "xprod16_tn_kernel");
+        xprod16_tn_kernel<NKQ, 0, 2><<<grid, XPROD_THREADS, lds2, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
+                                                                               (Cx ? Cx : h->Cx) + p.col_off, ldc, slab_stride ? slab_stride : (size_t)KP * ldc,
+                                                                               p.stage_begin, p.stage_end, p.sps, h->scal_exp);
+        return;
+    }
     const int lds = xprod_tn_lds_bytes(KP);
     set_dyn_lds((const void *)xprod16_tn_kernel<NKQ>, lds, "xprod16_tn_kernel");
     xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
@@ -970,8 +979,8 @@ static void launch_sweep_m(int method, const SweepArgs &a, hipStream_t s)
 {
     const int cpw = 64 / L; // columns per wavefront
     const int nb = (a.ncols + cpw - 1) / cpw;
-    if (method == 1) sweep_ls_kernel<R, L, 1><<<nb, 64, 0, s>>>(a);
-    else sweep_ls_kernel<R, L, 2><<<nb, 64, 0, s>>>(a);
+    (void)method; // Lee's multiplicative updates only: SCD-LS is sweep_scd_q_kernel at every rank <= 64 (launch_sweep)
+    sweep_ls_kernel<R, L, 2><<<nb, 64, 0, s>>>(a);
 }
 
 // registers per lane R = STEP * idx, idx = 1..8
