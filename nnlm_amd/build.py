@@ -1,4 +1,8 @@
-"""Build libnnlm_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libnnlm_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is a handful of translation units (nnlm_amd/csrc/*.hip) compiled in parallel and linked into one shared object: the SCD
+sweep kernels of k_sweep_q.h (one heavy instantiation per block count, mask and arithmetic mode) take as long as everything else
+together, so they have units of their own (tu_sweepq.hip, tu_sweepqw.hip)."""
 from __future__ import annotations
 
 import os
@@ -6,13 +10,17 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "nnlm_mi355x.hip")
+CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnnlm_mi355x.so")
+OBJ = os.path.join(HERE, "build")
+
+
+def units():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 
 
 def sources():
-    d = os.path.join(HERE, "csrc")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))] + [
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [
         os.path.join(HERE, "..", "include", "nnlm_mi355x.h")]
 
 
@@ -20,13 +28,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
     # -amdgpu-mfma-vgpr-form: keep MFMA C/D operands in VGPRs (gfx950 has a unified register file); the sweep kernel
     # reads and rewrites single accumulator entries between MFMAs and would otherwise shuttle whole tiles VGPR<->AGPR
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-shared", "-fPIC", "-o", OUT, SRC]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
+    procs = []
+    for src in units():  # every unit at once: a few processes, each minutes long
+        obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, obj, subprocess.Popen(cmd)))
+    objs = []
+    for cmd, obj, p in procs:
+        if p.wait() != 0:
+            for _, _, q in procs:
+                if q.poll() is None:
+                    q.kill()
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return OUT
 
 

@@ -49,7 +49,7 @@ __host__ __device__ static inline size_t sweepq_img_doubles(int NB, bool strict)
 //   strict only: s == NB + 1 : 1 / G[4 bn + kA][4 bn + kA],  s == NB + 2 : G[4 bn + kA][4 bn + kA]   (per-coordinate constants of the next block)
 // followed by rinv[q] = 1 / G[q][q], q < 4 NB.  G' = edited G (src/update_with_missing.cpp:20-24) with row r divided by its
 // diagonal (diagonal exactly 1) -- strict: the edited G itself; coordinates >= k are inert (identity).
-__global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1, int NB,
+static __global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1, int NB,
                                                           double *__restrict__ img, int strict)
 {
     const int NP = sweepq_np(NB, strict != 0);
@@ -398,4 +398,322 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && (NB >= 15 || (STRICT 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sq_smem[]; // sweepq_lds_bytes(KP, NB, STRICT)
     sweepq16_body<NT, NB, HAS_MASK, STRICT>(a, img, sq_smem);
+}
+
+// =====================================================================================================================================
+// Persistent form ("wrap"): the W half-step of the benchmark has 20000 columns = 1250 wavefronts of 16 for 1024 SIMDs.  A SIMD runs ONE
+// wavefront of this kernel at full speed -- a second one adds its whole time --, so the plain launch takes two
+// rounds on the 226 SIMDs that carry two wavefronts (0.205 ms) while 798 SIMDs idle through the second.  A column's sweeps are a
+// sequential chain, but the chain need not stay on one wavefront: with G column groups (of 16) per workgroup and its four wavefronts
+// as four machines, McNaughton's wrap-around rule for preemptive scheduling on identical machines -- lay the G chains of S sweeps end to
+// end on one time line, cut it into four pieces of T = ceil(G S / 4) -- gives every wavefront T sweeps of work instead of 2 S: a group cut
+// by a piece boundary has its FIRST sweeps run by the wavefront whose piece starts inside it (at the start of its time) and its LAST
+// sweeps by the wavefront whose piece ends inside it (at the end of its time); in between the group's state (x, gradients, the deltas
+// still owed, activity and sweep counts: 2 NB + 1 doubles per lane) waits in LDS.  The two parts never overlap in time (T >= S), the
+// consumer finds the state ready unless the producer was delayed (it then spins on an LDS flag), and no wavefront of a piece waits for
+// a wavefront that can wait for it: producers are first in their wavefront's order.  One workgroup per CU (the launch pads its LDS
+// request so that two cannot share one), 256 threads, one wavefront per SIMD at any time: G = 5 at the benchmark's W half-step, T = 63
+// sweeps instead of 100.  Same arithmetic, same order of operations per column as the plain form: results are bit-identical.
+// =====================================================================================================================================
+#define SWEEPQ_WRAP_MAXG 7
+__host__ __device__ static inline size_t sweepqw_slot_doubles(int NB) { return (size_t)(2 * NB + 1) * 64 + 64; } // per lane: x, gradients, owed deltas; (act, sweeps) as ints
+__host__ __device__ static inline size_t sweepqw_lds_bytes(int KP, int NB, bool strict, int G)
+{
+    return ((size_t)16 * G * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 3 * sweepqw_slot_doubles(NB)) * 8 + 64;
+}
+
+// sweepq_epilogue for a run-time number of columns (a multiple of 16)
+template <int NT> __device__ __forceinline__ void sweepqw_epilogue(const SweepArgs &a, const double *xl, int ncl, int col_base, int slab_idx)
+{
+    constexpr int KP = 16 * NT, XS = KP + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
+    float xmax = 0.0f;
+    for (int e = tid; e < ncl * KP; e += SWEEPQ_THREADS) {
+        const int q = e / ncl, c = e % ncl, ecol = col_base + c;
+        if (q < k && ecol < a.ncols) {
+            const double xv = xl[c * XS + q];
+            xmax = fmaxf(xmax, fabsf((float)xv));
+            a.Xout[(size_t)q * a.ldo + (ecol - a.ocol0)] = xv;
+            if (a.op_mode == 1) {
+                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + ecol] = xv;
+                else ((float *)a.op)[(size_t)q * a.op_ld + ecol] = (float)xv;
+            }
+        }
+    }
+    if (a.maxbits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
+    }
+    if (a.gram_slabs) {
+        const int l15 = lane & 15, lg = lane >> 4;
+        double *slab = a.gram_slabs + (size_t)slab_idx * KP * KP;
+        int tix = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+            for (int tb = ta; tb < NT; tb++) {
+                if ((tix++ & 3) != wave) continue;
+                f64x4 g = f64x4{0, 0, 0, 0};
+                for (int s4 = 0; s4 < ncl / 4; s4++) {
+                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = g[r];
+            }
+    }
+}
+
+template <int NT, int NB, bool HAS_MASK, bool STRICT>
+__global__ __launch_bounds__(SWEEPQ_THREADS, 1) void sweep_scd_qw_kernel(const SweepArgs a, const double *__restrict__ img, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sq_smem[]; // sweepqw_lds_bytes(KP, NB, STRICT, G) (or more: see the launch)
+    constexpr int KP = 16 * NT, NP = (NB + (STRICT ? 4 : 2)) / 2, XS = KP + 2;
+    static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 1, "NB = ceil(k / 4)");
+    const int SLOT = (int)sweepqw_slot_doubles(NB);
+    double *xl = (double *)sq_smem;             // [16 G][XS]: x[column][coordinate], final values
+    double *opl = xl + (size_t)16 * G * XS;     // [NB * NP * 32]: the operand image
+    double *hand = opl + NB * NP * 32;          // [3][SLOT]: slot w = state on its way from wavefront w + 1 to wavefront w
+    int *ready = (int *)(hand + 3 * SLOT);      // [3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ri = lane >> 4, c16 = lane & 15;
+    const int k = a.k;
+    const int col_wg = a.col0 + 16 * G * (int)blockIdx.x; // first column of the workgroup
+
+    for (int e = tid; e < NB * NP * 16; e += SWEEPQ_THREADS) ((f64x2 *)opl)[e] = ((const f64x2 *)img)[e];
+    if constexpr (KP > 4 * NB) { // coordinates beyond the last block
+        constexpr int REST = KP - 4 * NB;
+        for (int e = tid; e < 16 * G * REST; e += SWEEPQ_THREADS) xl[(e / REST) * XS + 4 * NB + e % REST] = 0.0;
+    }
+    if (tid < 3) ready[tid] = 0;
+    __syncthreads(); // operand image complete, flags clear
+    const double *rinv = img + (size_t)NB * NP * 32;
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const f64x2 *opv = (const f64x2 *)opl + (4 * (lane >> 4) + (lane & 3));
+    auto fetch = [&](auto bc, double(&set)[2 * NP]) {
+        constexpr int B = decltype(bc)::value;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const f64x2 v = opv[(B * NP + p) * 16];
+            set[2 * p] = v[0];
+            set[2 * p + 1] = v[1];
+        }
+    };
+    double As[2][2 * NP];
+    // ---- state of the group in hand -------------------------------------------------------------------------------------------
+    double acc[NB], x[NB];
+    double d_pend = 0.0;
+    bool act = false, in_range = false;
+    int t_lane = 0, col = 0, cl = 0;
+    unsigned long long mword = 0ull;
+    long long counted = 0; // sweeps of the columns this wavefront finished
+
+    auto write_col = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int q = 4 * b + ri;
+            double v = x[b];
+            if (HAS_MASK && in_range && q < k && ((mword >> q) & 1ull)) v = a.X[(size_t)q * a.ldx + col];
+            xl[cl * XS + q] = in_range ? v : 0.0;
+        }
+    };
+    auto select_group = [&](int gl) {
+        cl = 16 * gl + c16;
+        col = col_wg + cl;
+        in_range = col < a.ncols;
+        mword = 0ull;
+        if (HAS_MASK) mword = a.mask[in_range ? col : a.col0];
+    };
+    // the prologue of the plain form: x, nu = ((L1 - c) + G x) / diag, masks
+    auto init_fresh = [&]() {
+        const int cc = in_range ? col : a.col0;
+        act = in_range && !(HAS_MASK && ((mword & kmask) == kmask));
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int q = 4 * b + ri;
+            acc[b] = 0.0;
+            x[b] = (q < k && in_range) ? a.X[(size_t)q * a.ldx + col] : 0.0;
+        }
+        for (int s = 0; s < a.nslabs; s++) {
+            const double *cs = a.Cx + (size_t)s * a.slab_stride + cc;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int q = 4 * b + ri;
+                acc[b] += (q < k) ? cs[(size_t)q * a.ldc] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int q = 4 * b + ri;
+            acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - acc[b] : -acc[b]) * (STRICT ? 1.0 : rinv[q]) : 0.0;
+        }
+        sq_for<0, NB>([&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            fetch(bc, As[0]);
+#pragma unroll
+            for (int T = 0; T < NB; T++) acc[T] = sq_mfma(As[0][T], x[B], acc[T]);
+        });
+        if (HAS_MASK) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+                if ((mword >> (4 * b + ri)) & 1ull) x[b] = 0.0, acc[b] = 1e150;
+        }
+        d_pend = 0.0;
+        t_lane = 0;
+        if (!act) write_col();
+    };
+    auto store_state = [&](int slot) {
+        double *hv = hand + (size_t)slot * SLOT;
+#pragma unroll
+        for (int b = 0; b < NB; b++) hv[b * 64 + lane] = x[b], hv[(NB + b) * 64 + lane] = acc[b];
+        hv[2 * NB * 64 + lane] = d_pend;
+        int *hi = (int *)(hv + (2 * NB + 1) * 64);
+        hi[lane] = act ? 1 : 0;
+        hi[64 + lane] = t_lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ready[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto load_state = [&](int slot) {
+        while (__hip_atomic_load(&ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double *hv = hand + (size_t)slot * SLOT;
+#pragma unroll
+        for (int b = 0; b < NB; b++) x[b] = hv[b * 64 + lane], acc[b] = hv[(NB + b) * 64 + lane];
+        d_pend = hv[2 * NB * 64 + lane];
+        const int *hi = (const int *)(hv + (2 * NB + 1) * 64);
+        act = hi[lane] != 0;
+        t_lane = hi[64 + lane];
+    };
+
+    const double tol = a.rel_tol, tolh = 0.5 * tol, tolhe = 0.5 * tol * NNLM_TINY;
+    bool flag = false;
+    double Lc = 0.0, rinvc = 0.0, gdc = 0.0;
+    // One block -- identical to the step of the plain form (sweepq16_body: stages, hazards and scheduling barriers explained there)
+    auto step = [&](auto bc, auto tc) {
+        constexpr int B = decltype(bc)::value, BN = (B + 1) % NB;
+        constexpr bool TEST = decltype(tc)::value;
+        constexpr SqSched S = sq_sched(NB - 1);
+        double(&Ap)[2 * NP] = As[(B + 1) & 1];
+        double(&Ac)[2 * NP] = As[B & 1];
+        const double m0 = acc[B], xb = x[B];
+        auto lazies = [&](auto fromc, auto toc) {
+            sq_for<decltype(fromc)::value, decltype(toc)::value>([&](auto oc) {
+                constexpr int T = (B + 1 + decltype(oc)::value) % NB;
+                acc[T] = sq_mfma(Ap[T], d_pend, acc[T]);
+            });
+        };
+#define SQ_IC(v) std::integral_constant<int, (v)> {}
+#define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if constexpr (STRICT) {                                                                                             \
+        const double q0 = (val_in) * rinvc;                                                                             \
+        const double qq = __builtin_fma(__builtin_fma(-q0, gdc, (val_in)), rinvc, q0);                                  \
+        tmpx = __builtin_fmax(xb - qq, 0.0);                                                                            \
+        c = tmpx - xb;                                                                                                  \
+    } else                                                                                                              \
+        c = sq_delta(xb, val_in);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
+    lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    dep_expr;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
+    sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+        double c, m, tmpx = 0.0;
+        SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))
+        fetch(bc, Ac);
+        SQ_STAGE(1, m, m = sq_mfma(Lc, c, m0))
+        SQ_STAGE(2, m, m = sq_mfma(Lc, c, m0))
+        SQ_STAGE(3, m, acc[BN] = sq_mfma(Ac[BN], c, acc[BN]))
+#undef SQ_STAGE
+#undef SQ_IC
+        const double d = c;
+        if (TEST) {
+            if constexpr (STRICT) flag |= rel_change_exceeds(2.0 * fabs(d), tmpx + xb + NNLM_TINY, tol);
+            else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
+        }
+        x[B] = STRICT ? tmpx : xb + d;
+        d_pend = d;
+        Lc = Ac[NB];
+        if constexpr (STRICT) rinvc = Ac[NB + 1], gdc = Ac[NB + 2];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tests_needed = [&]() -> bool {
+        const unsigned long long bal = __ballot(flag);
+        const unsigned cf = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+        return __any(act && !((cf >> c16) & 1u));
+    };
+    // sweeps [t0, t1) of the group in hand
+    auto run_sweeps = [&](unsigned t0, unsigned t1) {
+        unsigned t = t0;
+        bool go = t < t1 && __any(act);
+        fetch(std::integral_constant<int, NB - 1>{}, As[1]); // entering step 0: operands of block NB - 1, chain operand of block 0
+        Lc = As[1][NB];
+        rinvc = STRICT ? As[1][NB + 1] : 0.0, gdc = STRICT ? As[1][NB + 2] : 0.0;
+        sq_nop<8>();
+        while (go) {
+            flag = 0.0 > tol;
+            step(std::integral_constant<int, 0>{}, std::true_type{});
+            if (tests_needed()) {
+                sq_for<1, NB>([&](auto bc) { step(bc, std::true_type{}); });
+            } else {
+                sq_for<1, NB>([&](auto bc) { step(bc, std::false_type{}); });
+            }
+            if constexpr (NB & 1) {
+#pragma unroll
+                for (int s = 0; s < 2 * NP; s++) As[1][s] = As[0][s];
+            }
+            const unsigned long long bal = __ballot(flag);
+            const unsigned cf = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+            if (act) {
+                t_lane++;
+                if (!((cf >> c16) & 1u)) {
+                    write_col();
+                    act = false;
+                }
+            }
+            t++;
+            go = t < t1 && __any(act);
+        }
+    };
+    auto finish_group = [&]() { // the column's last sweeps were run here
+        if (act) write_col();
+        counted += (ri == 0) ? (long long)t_lane : 0ll;
+    };
+
+    // ---- this wavefront's piece [lo, hi) of the time line of G groups x S sweeps ------------------------------------------------
+    const long long S = (long long)a.max_iter, T = (S * G + 3) / 4;
+    const long long lo = (long long)wave * T, hi_raw = lo + T, tot = S * G;
+    const long long hi = hi_raw < tot ? hi_raw : tot;
+    // (ONE loop over the wavefront's parts of groups with ONE call of the sweep loop: each call site would be another inlined copy of it)
+    for (long long pos = lo; pos < hi;) {
+        const int gl = (int)(pos / S);
+        const long long gbeg = (long long)gl * S, gend = gbeg + S;
+        const bool head = pos != gbeg;            // the piece starts inside the group: its FIRST sweeps, then the state goes to the wavefront below
+        const long long end = gend < hi ? gend : hi;
+        const bool tail = !head && end != gend;   // the piece ends inside the group: its LAST sweeps, on the state the wavefront above leaves behind
+        select_group(gl);
+        unsigned t0 = 0u, t1 = (unsigned)S;
+        if (tail) {
+            load_state(wave);
+            t0 = (unsigned)(S - (end - pos));
+        } else {
+            init_fresh();
+            if (head) t1 = (unsigned)(gend - pos);
+        }
+        run_sweeps(t0, t1);
+        if (head) store_state(wave - 1);
+        else finish_group();
+        pos = head ? gend : end;
+    }
+    __syncthreads(); // x image final
+
+    sweepqw_epilogue<NT>(a, xl, 16 * G, col_wg, (int)blockIdx.x);
+    {
+        const long long totc = wave_sum_ll(counted);
+        if (lane == 0 && totc) atomicAdd(a.sweeps, (unsigned long long)totc);
+    }
 }

@@ -21,6 +21,7 @@
 #include "k_sweep_q.h"
 #include "k_xprod.h"
 #include "k_xprod16.h"
+#include "tu_sweepq.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -48,6 +49,8 @@ struct ProfRec {
 
 struct nnlm_handle {
     int device = 0;
+    int cus = 256;              // compute units of the device (sweep launch policy: one wavefront of the SCD sweep per SIMD, 4 SIMDs per CU)
+    int sweep_wgs = 0;          // workgroups of the last sweep_scd_q(w)_kernel launch = Gram partial-sum slabs it left behind
     int prec = NNLM_PREC_F32;
     hipStream_t stream = nullptr;   // main: cross products, solvers
     hipStream_t stream_e = nullptr; // error block, concurrent with the (speculative) next W half-step
@@ -297,6 +300,9 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     nnlm_handle *h = new nnlm_handle();
     h->device = device;
     h->prec = precision;
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("NNLM_DEBUG_CUS")) // test hook: pretend the device has this many CUs (the sweep's launch policy at small sizes)
+        if (atoi(e) > 0) h->cus = atoi(e);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_hdone, hipEventDisableTiming) != hipSuccess ||
@@ -1015,46 +1021,35 @@ static int sweep_lanes_per_column(int ncols)
 // fp64 mode: the reference's arithmetic (correctly rounded mu / G[q][q]).
 static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX; }
 
-template <int NT, int NB, bool M, bool S> static void launch_sweep_q_k(nnlm_handle *h, const SweepArgs &a, int nb)
-{
-    const int lds = (int)sweepq_lds_bytes(16 * NT, NB, S); // x image + operand image (up to 75 KB at k = 64)
-    set_dyn_lds((const void *)sweep_scd_q_kernel<NT, NB, M, S>, lds, "sweep_scd_q_kernel");
-    sweep_scd_q_kernel<NT, NB, M, S><<<nb, SWEEPQ_THREADS, lds, h->stream>>>(a, h->sweepq_img);
-}
-template <int NT, int NB> static void launch_sweep_q_m(nnlm_handle *h, const SweepArgs &a, int nb)
-{
-    if (h->prec == NNLM_PREC_F64) {
-        if (a.mask) launch_sweep_q_k<NT, NB, true, true>(h, a, nb);
-        else launch_sweep_q_k<NT, NB, false, true>(h, a, nb);
-    } else {
-        if (a.mask) launch_sweep_q_k<NT, NB, true, false>(h, a, nb);
-        else launch_sweep_q_k<NT, NB, false, false>(h, a, nb);
-    }
-}
+// (the instantiations of sweep_scd_q_kernel / sweep_scd_qw_kernel -- 64 + 32 heavy ones -- live in translation units of their own,
+//  tu_sweepq.hip / tu_sweepqw.hip, compiled next to this one: tu_sweepq.h)
 static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
 {
-    const int nb = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS, NB = (a.k + 3) / 4;
+    int nb = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
+    const int NB = (a.k + 3) / 4;
+    h->sweep_wgs = 0;
     if (nb <= 0) return;
     if (!h->pack_ready)
         sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img, h->prec == NNLM_PREC_F64 ? 1 : 0);
     h->pack_ready = false;
-    switch (NB) {
-    case 1: launch_sweep_q_m<1, 1>(h, a, nb); break;
-    case 2: launch_sweep_q_m<1, 2>(h, a, nb); break;
-    case 3: launch_sweep_q_m<1, 3>(h, a, nb); break;
-    case 4: launch_sweep_q_m<1, 4>(h, a, nb); break;
-    case 5: launch_sweep_q_m<2, 5>(h, a, nb); break;
-    case 6: launch_sweep_q_m<2, 6>(h, a, nb); break;
-    case 7: launch_sweep_q_m<2, 7>(h, a, nb); break;
-    case 8: launch_sweep_q_m<2, 8>(h, a, nb); break;
-    case 9: launch_sweep_q_m<3, 9>(h, a, nb); break;
-    case 10: launch_sweep_q_m<3, 10>(h, a, nb); break;
-    case 11: launch_sweep_q_m<3, 11>(h, a, nb); break;
-    case 12: launch_sweep_q_m<3, 12>(h, a, nb); break;
-    case 13: launch_sweep_q_m<4, 13>(h, a, nb); break;
-    case 14: launch_sweep_q_m<4, 14>(h, a, nb); break;
-    case 15: launch_sweep_q_m<4, 15>(h, a, nb); break;
-    default: launch_sweep_q_m<4, 16>(h, a, nb); break;
+    // Launch policy.  A SIMD runs one wavefront (16 columns) of this sweep at full speed and a second one adds its whole time.  Up to
+    // one wavefront per SIMD: the plain form.  Between one and two (the benchmark's W half-step: 1250 for 1024): the persistent form,
+    // whose wavefronts share G = 5 .. 7 column groups per CU by the wrap-around rule -- ceil(G S / 4) sweeps of work per SIMD instead
+    // of 2 S.  Beyond: the plain form again (several balanced rounds).
+    const int ngroups = (a.ncols - a.col0 + 15) / 16, simds = 4 * h->cus;
+    int G = 0;
+    if (ngroups > simds && a.max_iter >= 4) {
+        G = (ngroups + h->cus - 1) / h->cus;
+        // (masked factors with that many columns stay on the plain form: the persistent one is not instantiated for them)
+        if (G < 5 || G > SWEEPQ_WRAP_MAXG || a.mask || sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, G) > (size_t)160 * 1024) G = 0;
+    }
+    if (G) nb = (ngroups + G - 1) / G;
+    h->sweep_wgs = nb;
+    const bool strict = h->prec == NNLM_PREC_F64;
+    const hipError_t ea = G ? nnlm_tu_sweep_qw(a, h->sweepq_img, nb, NB, strict, G, h->stream) : nnlm_tu_sweep_q(a, h->sweepq_img, nb, NB, strict, h->stream);
+    if (ea != hipSuccess && g_attr_err == hipSuccess) {
+        g_attr_err = ea;
+        g_attr_what = G ? "sweep_scd_qw_kernel" : "sweep_scd_q_kernel";
     }
 }
 
@@ -1983,11 +1978,11 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             int rcs = launch_sweep(h, method, a);
             if (rcs != NNLM_OK) return rcs;
             if (h->sharded && h->pack_tail) {
-                const int nsl = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
+                const int nsl = h->sweep_wgs; // (one slab per workgroup of the sweep launch)
                 gram_fold_tail_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, nsl, h->KP, h->pack_send + (size_t)h->k * a.ldo, h->maxbits + 8);
             }
             if (sg) { // the next half-step finds max and Gram partial sums of this factor
-                h->sg_nslabs = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
+                h->sg_nslabs = h->sweep_wgs; // (one slab per workgroup of the sweep launch)
                 h->sg_par ^= 1;
                 h->sg_which = which;
                 h->sg_other = h->sg_prev; // the word this sweep did not touch

@@ -1,0 +1,37 @@
+// tu_sweepq.hip -- the instantiations of sweep_scd_q_kernel (k_sweep_q.h), see tu_sweepq.h.
+#include "tu_sweepq.h"
+#include "k_sweep_q.h"
+
+template <int NT, int NB, bool M, bool S> static hipError_t launch_k(const SweepArgs &a, const double *img, int nb, hipStream_t st)
+{
+    const int lds = (int)sweepq_lds_bytes(16 * NT, NB, S); // x image + operand image (up to 75 KB at k = 64)
+    const hipError_t e = hipFuncSetAttribute((const void *)sweep_scd_q_kernel<NT, NB, M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    sweep_scd_q_kernel<NT, NB, M, S><<<nb, SWEEPQ_THREADS, lds, st>>>(a, img);
+    return e;
+}
+template <int NT, int NB> static hipError_t launch_m(const SweepArgs &a, const double *img, int nb, bool strict, hipStream_t st)
+{
+    if (strict) return a.mask ? launch_k<NT, NB, true, true>(a, img, nb, st) : launch_k<NT, NB, false, true>(a, img, nb, st);
+    return a.mask ? launch_k<NT, NB, true, false>(a, img, nb, st) : launch_k<NT, NB, false, false>(a, img, nb, st);
+}
+hipError_t nnlm_tu_sweep_q(const SweepArgs &a, const double *img, int nb, int NB, bool strict, hipStream_t st)
+{
+    switch (NB) {
+    case 1: return launch_m<1, 1>(a, img, nb, strict, st);
+    case 2: return launch_m<1, 2>(a, img, nb, strict, st);
+    case 3: return launch_m<1, 3>(a, img, nb, strict, st);
+    case 4: return launch_m<1, 4>(a, img, nb, strict, st);
+    case 5: return launch_m<2, 5>(a, img, nb, strict, st);
+    case 6: return launch_m<2, 6>(a, img, nb, strict, st);
+    case 7: return launch_m<2, 7>(a, img, nb, strict, st);
+    case 8: return launch_m<2, 8>(a, img, nb, strict, st);
+    case 9: return launch_m<3, 9>(a, img, nb, strict, st);
+    case 10: return launch_m<3, 10>(a, img, nb, strict, st);
+    case 11: return launch_m<3, 11>(a, img, nb, strict, st);
+    case 12: return launch_m<3, 12>(a, img, nb, strict, st);
+    case 13: return launch_m<4, 13>(a, img, nb, strict, st);
+    case 14: return launch_m<4, 14>(a, img, nb, strict, st);
+    case 15: return launch_m<4, 15>(a, img, nb, strict, st);
+    default: return launch_m<4, 16>(a, img, nb, strict, st);
+    }
+}

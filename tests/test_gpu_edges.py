@@ -97,7 +97,7 @@ def test_infinite_entries_of_y_are_missing_values_in_nnlm(monkeypatch, pname, en
     r_nan = nnlm_amd.c_nnlm(x, y_nan, z, None, b0, sweeps, 1e-8, 1, 1)
     assert np.array_equal(r_inf["coefficient"], r_nan["coefficient"]) and r_inf["n_iteration"] == r_nan["n_iteration"]
     o = ref.c_nnlm(x, y_inf, z, None, b0, sweeps, 1e-8, 1, 1)
-    assert relF(r_inf["coefficient"], o["coefficient"]) < max(tol, 1e-7)
+    assert relF(r_inf["coefficient"], o["coefficient"]) < tol
     if pname == "f64":
         assert r_inf["n_iteration"] == o["n_iteration"]
 
@@ -118,7 +118,9 @@ def test_fp32_operand_mode_refuses_magnitudes_it_cannot_hold_and_the_strict_mode
             h.set_matrix(A)  # the handle stays usable
             h.set_factors(5, W0, H0)
             h.iterate(1, z, z, 5, 1e-9, 1)
-    for scale in (1e40, 1e-36):  # every entry outside the fp32 range
+    # (the other end is not a test case for ANY arithmetic: with every entry near 1e-36 the Gram diagonals are ~1e-34, far below the
+    #  reference's own 1e-16 on the diagonal (src/update_with_missing.cpp:24), and the iteration collapses to rounding dust)
+    for scale in (1e40,):  # every entry beyond FLT_MAX
         As, Ws, Hs = A * scale, W0 * np.sqrt(scale), H0 * np.sqrt(scale)
         with nnlm_amd.Handle(0, _lib.PREC_F64) as h:
             h.set_matrix(As)

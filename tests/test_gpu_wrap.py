@@ -1,0 +1,74 @@
+"""The persistent ("wrap-around") form of the SCD sweep (k_sweep_q.h, sweep_scd_qw_kernel): between one and two wavefronts of 16
+columns per SIMD the launch gives every CU G = 5 .. 7 column groups, which its four wavefronts share by McNaughton's rule -- a group
+cut by a piece boundary is started by one wavefront and finished by another, its state handed over through LDS.  Same arithmetic per
+column as the plain form, so the results must be BIT-IDENTICAL to it: the device is made to look small (NNLM_DEBUG_CUS, read by
+nnlm_create) so that a few hundred columns take the persistent form, and the same problem is run on the plain form for comparison;
+both are also held against the oracle.  The benchmark's W half-step (20000 columns on 256 CUs: G = 5) takes this form at full size
+(tests/test_gpu_fullsize.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import relF  # noqa: E402
+import nnlm_amd  # noqa: E402
+from nnlm_amd import _lib  # noqa: E402
+from oracle import ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, cus, prec, A, k, W0, H0, Wm, Hm, reg, inner, tol, iters):
+    """(W, H, sweeps) after `iters` outer iterations; iters = 'W' / 'H': ONE half-step from the given factors."""
+    if cus:
+        monkeypatch.setenv("NNLM_DEBUG_CUS", str(cus))
+    else:
+        monkeypatch.delenv("NNLM_DEBUG_CUS", raising=False)
+    with nnlm_amd.Handle(0, prec) as h:
+        h.set_matrix(A)
+        h.set_factors(k, W0, H0, Wm, Hm)
+        if iters in ("W", "H"):
+            h.half_step(0 if iters == "W" else 1, reg, inner, tol, 1)
+        else:
+            h.iterate(iters, reg, reg, inner, tol, 1)
+        W, H = h.get_factors()
+        sw = h.take_sweeps()
+    return W, H, sw
+
+
+@pytest.mark.parametrize("pname,prec,otol", [("f64", _lib.PREC_F64, 1e-9), ("f32", _lib.PREC_F32, 1e-4)])
+@pytest.mark.parametrize("cus,n,m", [(2, 150, 224), (2, 208, 190), (3, 260, 330), (1, 70, 112), (2, 129, 161)])  # G = 5 .. 7 each way, ragged ends
+@pytest.mark.parametrize("k,masks,inner,itol", [(50, False, 50, 1e-9), (7, True, 9, 1e-9), (64, True, 6, 1e-2), (33, False, 50, 1e-3), (3, False, 4, -1.0),
+                                                 (57, True, 12, 1e-9)])
+def test_persistent_sweep_is_bit_identical_to_the_plain_form(monkeypatch, pname, prec, otol, cus, n, m, k, masks, inner, itol):
+    rng = np.random.default_rng(1000 * k + n + cus)
+    kk = min(k, n, m)
+    Wp, Hp = rng.random((n, kk + 2)) ** 2 + 0.05, rng.random((kk + 2, m)) ** 2 + 0.05
+    A = Wp @ Hp / (kk + 2) * 4 + 0.02 * rng.random((n, m)) + 0.01
+    sc = 2.0 / np.sqrt(kk + 2)
+    W0, H0 = Wp[:, :kk] * sc * (0.7 + 0.6 * rng.random((n, kk))), Hp[:kk, :] * sc * (0.7 + 0.6 * rng.random((kk, m)))
+    Wm = Hm = None
+    if masks:
+        Wm, Hm = rng.random((n, kk)) < 0.1, rng.random((kk, m)) < 0.1
+        Wm[3, :] = True  # a column of the W half-step with every coordinate masked: skipped (src/update_with_missing.cpp:33)
+        W0[Wm] = 0.0
+        H0[Hm] = 0.0
+    reg = [0.01, 0.0, 0.005]
+    # one half-step from the same factors, each orientation: the same operations per column in the same order -- bit for bit
+    for which in ("W", "H"):
+        Ww, Hw, sww = _run(monkeypatch, cus, prec, A, kk, W0, H0, Wm, Hm, reg, inner, itol, which)
+        Wp_, Hp_, swp = _run(monkeypatch, 0, prec, A, kk, W0, H0, Wm, Hm, reg, inner, itol, which)
+        assert np.array_equal(Ww, Wp_) and np.array_equal(Hw, Hp_), (which, relF(Ww, Wp_), relF(Hw, Hp_))
+        assert sww == swp
+    # two iterations: the Gram partial sums a sweep leaves behind are per workgroup, 16 G columns here and 64 there, so the next
+    # half-step's Gram is the same sum in another order (1e-16): close, not identical; both against the oracle
+    Ww, Hw, sww = _run(monkeypatch, cus, prec, A, kk, W0, H0, Wm, Hm, reg, inner, itol, 2)
+    Wp_, Hp_, swp = _run(monkeypatch, 0, prec, A, kk, W0, H0, Wm, Hm, reg, inner, itol, 2)
+    close = 1e-10 if pname == "f64" else 1e-5
+    assert relF(Ww, Wp_) < close and relF(Hw, Hp_) < close, (relF(Ww, Wp_), relF(Hw, Hp_))
+    o = ref.c_nnmf(A, kk, W0, H0, Wm, Hm, reg, reg, 2, -1.0, 0, 0, False, inner, itol, 1, 2)
+    assert relF(Ww, o["W"]) < otol and relF(Hw, o["H"]) < otol
+    if pname == "f64" and itol < 1e-6:  # (sweep counts at a loose inner tolerance ride on rounding)
+        assert sww == int(round(float(np.sum(o["average_epoch"])) * (n + m)))

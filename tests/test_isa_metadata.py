@@ -29,12 +29,20 @@ ALLOWED_SCRATCH = {
 
 def kernel_table():
     """[(demangled name, vgprs, agprs, sgprs, scratch bytes, vgpr spills, lds bytes)] of every kernel in the gfx950 code object."""
+    notes = ""
     with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        fat = os.path.join(d, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, SO])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"  # one bundle per translation unit of the library (nnlm_amd/build.py)
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        assert starts, "no offload bundle in .hip_fatbin"
+        for n, (b0, b1) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+            part, co = os.path.join(d, f"fat{n}.bin"), os.path.join(d, f"dev{n}.co")
+            open(part, "wb").write(blob[b0:b1])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout + "\n"
     rows = []
     for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
         blk = ".agpr_count" + blk
