@@ -8,6 +8,7 @@
 // Work is O(k^2 n) = 1e8 flops at config 2 -- off the roofline; these kernels only have to be short.
 #pragma once
 #include "common.h"
+#include "k_sweep.h"
 
 #define GRAM_COLS_PER_BLOCK 256
 
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double *__restr
 // G = sum of MANY slabs (one per workgroup of the fast sweep kernel, k_sweep_q.h: hundreds), no fences, fixed order:
 // a block owns 64 consecutive entries, its 16 wavefronts add every 16th slab (coalesced 512-byte reads), LDS folds the
 // 16 partial sums in index order.  Launch with KP*KP/64 blocks of 1024 threads.  Lower tiles are written as mirrors.
-__device__ static inline void gram_fold_body(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G, int blk)
+__device__ static inline void gram_fold_body(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G, int blk,
+                                             const SweepImg &im)
 {
     __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -111,11 +113,16 @@ __device__ static inline void gram_fold_body(const double *__restrict__ slabs, i
         for (int j = 1; j < 16; j++) t += part[j][lane];
         G[e] = t;
         if ((a >> 4) < (b >> 4)) G[(size_t)b * KP + a] = t;
+        if (im.img) {
+            sweepq_img_put(im, a, b, t);
+            if ((a >> 4) < (b >> 4)) sweepq_img_put(im, b, a, t);
+        }
     }
 }
-__global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G)
+// im.img != NULL: also the SCD sweep's operand image (no sweepq_pack_kernel launch)
+__global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G, const SweepImg im)
 {
-    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
+    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x, im);
 }
 
 // The same fold for the Gram partial sums that travel behind a rank's packed slab (multi-GPU, dense SCD, column form), plus the
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(1024) void gram_fold_kernel(const double *__restric
 __global__ __launch_bounds__(1024) void gram_fold_tail_kernel(const double *__restrict__ slabs, int nslabs, int KP, double *__restrict__ G,
                                                               unsigned *__restrict__ maxword)
 {
-    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
+    gram_fold_body(slabs, nslabs, KP, G, blockIdx.x, SweepImg{});
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         G[(size_t)KP * KP] = (double)__uint_as_float(*maxword);
         *maxword = 0u;

@@ -62,6 +62,36 @@ struct SweepArgs {
     double *gram_slabs = nullptr;     // [workgroups][KP*KP]  Gram of each workgroup's 48 columns (upper tiles)
 };
 
+// The SCD sweep's operand image (k_sweep_q.h), written straight from the fold: SweepImg describes it, sweepq_img_put() stores the
+// edited Gram entry E[r][c] (src/update_with_missing.cpp:20-24: + r0 - r1 on the diagonal, + r1 everywhere, + 1e-16 on the diagonal;
+// coordinates >= k inert) into the slot(s) of the image that hold it.  Layout: k_sweep_q.h.  img == NULL: no image.
+struct SweepImg {
+    double *img = nullptr;
+    int NB = 0, NP = 0, k = 0;
+    double r0 = 0.0, r1 = 0.0;
+};
+__device__ static inline void sweepq_img_put(const SweepImg &im, int r, int c, double graw)
+{
+    const int NB = im.NB, NP = im.NP;
+    if (r >= 4 * NB || c >= 4 * NB) return;
+    double v;
+    if (r >= im.k || c >= im.k) v = (r == c) ? 1.0 : 0.0;
+    else {
+        v = graw;
+        if (r == c && im.r0 != im.r1) v += im.r0 - im.r1;
+        if (im.r1 != 0) v += im.r1;
+        if (r == c) v += NNLM_TINY;
+    }
+    const int s = r >> 2, iA = r & 3, beta = c >> 2, kA = c & 3;
+    im.img[(((size_t)beta * NP + (s >> 1)) * 16 + 4 * kA + iA) * 2 + (s & 1)] = v;         // operand of accumulator s for the deltas of block beta
+    if (s == beta) {                                                                       // the block's own 4 x 4 piece: chain operand (strictly lower part)
+        const int bprev = (s + NB - 1) % NB;                                               // stored with the block that precedes it
+        im.img[(((size_t)bprev * NP + (NB >> 1)) * 16 + 4 * kA + iA) * 2 + (NB & 1)] = (iA > kA) ? v : 0.0;
+        if (r == c) im.img[(size_t)NB * NP * 32 + r] = v;                                  // the diagonal, behind the operands
+    }
+}
+
+
 typedef double f64x16 __attribute__((ext_vector_type(16)));
 #define SWEEP_CH 16 // registers per indexable chunk (32 VGPRs: the largest s_set_gpr_idx-addressable vector)
 

@@ -43,41 +43,52 @@
 __host__ __device__ static inline int sweepq_np(int NB, bool strict) { return (NB + (strict ? 4 : 2)) / 2; } // operand PAIRS per step
 __host__ __device__ static inline size_t sweepq_img_doubles(int NB, bool strict) { return (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB; }
 
-// Operand image, exactly as the kernel keeps it in LDS: img[((beta * NP + p) * 16 + li) * 2 + e], li = 4 kA + iA, entry s = 2 p + e:
-//   s < NB  : G'[4 s + iA][4 beta + kA]                       (operand of accumulator s for the deltas of block beta)
-//   s == NB : strictly lower part of G'[4 bn + iA][4 bn + kA], bn = (beta + 1) % NB   (chain operand of the NEXT block)
-//   strict only: s == NB + 1 : 1 / G[4 bn + kA][4 bn + kA],  s == NB + 2 : G[4 bn + kA][4 bn + kA]   (per-coordinate constants of the next block)
-// followed by rinv[q] = 1 / G[q][q], q < 4 NB.  G' = edited G (src/update_with_missing.cpp:20-24) with row r divided by its
-// diagonal (diagonal exactly 1) -- strict: the edited G itself; coordinates >= k are inert (identity).
+// Operand image in memory ("raw": edited, not yet scaled), img[((beta * NP + p) * 16 + li) * 2 + e], li = 4 kA + iA, entry s = 2 p + e:
+//   s < NB  : E[4 s + iA][4 beta + kA]                        (operand of accumulator s for the deltas of block beta)
+//   s == NB : strictly lower part of E[4 bn + iA][4 bn + kA], bn = (beta + 1) % NB   (chain operand of the NEXT block)
+//   strict only: s == NB + 1, NB + 2: unused here (filled in LDS: 1 / E[q][q] and E[q][q] of the next block's coordinates q = 4 bn + kA)
+// followed by the diagonal E[q][q], q < 4 NB.  E = edited G (src/update_with_missing.cpp:20-24); coordinates >= k are inert (identity).
+// Written by sweepq_img_put() (k_gram.h) -- from the fold of the Gram partial sums (gram_fold_kernel / factor16_fold_kernel: no launch
+// of its own in the steady state of the dense flows) or by sweepq_pack_kernel below.  The sweep kernels turn it into the image they
+// keep in LDS while they copy it (sweepq_load_image): fp32-operand mode: row r divided by its diagonal, G' = E[r][c] * (1 / E[r][r]),
+// diagonal exactly 1; strict: E itself plus the per-coordinate constants.
 static __global__ __launch_bounds__(256) void sweepq_pack_kernel(const double *__restrict__ Graw, int KPg, int k, double r0, double r1, int NB,
                                                           double *__restrict__ img, int strict)
 {
-    const int NP = sweepq_np(NB, strict != 0);
-    auto edited = [&](int c, int kc) -> double {
-        if (c >= k || kc >= k) return (c == kc) ? 1.0 : 0.0;
-        double g = Graw[(size_t)c * KPg + kc];
-        if (c == kc && r0 != r1) g += r0 - r1;
-        if (r1 != 0) g += r1;
-        if (c == kc) g += NNLM_TINY;
-        return g;
-    };
-    auto scaled = [&](int r, int c) -> double { return strict ? edited(r, c) : ((r == c) ? 1.0 : edited(r, c) * (1.0 / edited(r, r))); };
-    const int total = NB * NP * 32;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total + 4 * NB; e += gridDim.x * 256) {
-        if (e >= total) {
-            img[e] = 1.0 / edited(e - total, e - total);
-            continue;
-        }
-        const int s = 2 * ((e >> 5) % NP) + (e & 1), beta = (e >> 5) / NP, li = (e >> 1) & 15, kA = li >> 2, iA = li & 3;
-        double v = 0.0;
-        if (s < NB) v = scaled(4 * s + iA, 4 * beta + kA);
-        else if (s <= NB + 2) {
-            const int bn = (beta + 1) % NB;
-            if (s == NB) v = (iA > kA) ? scaled(4 * bn + iA, 4 * bn + kA) : 0.0;
-            else if (strict) v = (s == NB + 1) ? 1.0 / edited(4 * bn + kA, 4 * bn + kA) : edited(4 * bn + kA, 4 * bn + kA);
-        }
-        img[e] = v;
+    SweepImg im;
+    im.img = img, im.NB = NB, im.NP = sweepq_np(NB, strict != 0), im.k = k, im.r0 = r0, im.r1 = r1;
+    const int n = 4 * NB;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n; e += gridDim.x * 256) {
+        const int r = e / n, c = e % n;
+        sweepq_img_put(im, r, c, (r < k && c < k) ? Graw[(size_t)r * KPg + c] : 0.0);
     }
+}
+
+// memory image -> the workgroup's LDS image opl[NB * NP * 32] and rinv_l[4 NB] = 1 / E[q][q] (all threads; ends with a barrier)
+template <int NB, bool STRICT> __device__ __forceinline__ void sweepq_load_image(const double *__restrict__ img, double *opl, double *rinv_l)
+{
+    constexpr int NP = (NB + (STRICT ? 4 : 2)) / 2;
+    const int tid = threadIdx.x;
+    const double *diag = img + (size_t)NB * NP * 32;
+    if (tid < 4 * NB) rinv_l[tid] = 1.0 / diag[tid];
+    __syncthreads();
+    for (int e = tid; e < NB * NP * 16; e += SWEEPQ_THREADS) {
+        f64x2 v = ((const f64x2 *)img)[e];
+        const int li = e & 15, p = (e >> 4) % NP, beta = (e >> 4) / NP, kA = li >> 2, iA = li & 3, bn = (beta + 1) % NB;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int s = 2 * p + h;
+            if (s < NB) {
+                if (!STRICT) v[h] = (4 * s + iA == 4 * beta + kA) ? 1.0 : v[h] * rinv_l[4 * s + iA];
+            } else if (s == NB) {
+                if (!STRICT) v[h] = v[h] * rinv_l[4 * bn + iA]; // (strictly lower part: never the diagonal)
+            } else if (STRICT && s == NB + 1) v[h] = rinv_l[4 * bn + kA];
+            else if (STRICT && s == NB + 2) v[h] = diag[4 * bn + kA];
+            else v[h] = 0.0;
+        }
+        ((f64x2 *)opl)[e] = v;
+    }
+    __syncthreads();
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void sq_for(F &&f)
@@ -175,7 +186,7 @@ template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(cons
 }
 
 // LDS of one 16-column-per-wavefront workgroup: the x image and the operand image
-__host__ __device__ static inline size_t sweepq_lds_bytes(int KP, int NB, bool strict) { return ((size_t)SWEEPQ_COLS * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32) * 8; }
+__host__ __device__ static inline size_t sweepq_lds_bytes(int KP, int NB, bool strict) { return ((size_t)SWEEPQ_COLS * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB) * 8; }
 
 // NT: the caller's rank padding KP = 16 NT (layout of the outputs and of the Gram slabs); NB = ceil(k / 4) blocks.
 // Workgroup blockIdx.x of the launch.  (A device function + sweepq_epilogue: scripts/exp/k_sweep_q4.h mixes it with a second
@@ -195,8 +206,8 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
     const bool in_range = col < a.ncols;
     const int cc = in_range ? col : a.col0;
 
-    for (int e = tid; e < NB * NP * 16; e += SWEEPQ_THREADS) ((f64x2 *)opl)[e] = ((const f64x2 *)img)[e];
-    const double *rinv = img + (size_t)NB * NP * 32;
+    double *rinv = opl + NB * NP * 32; // [4 NB]: 1 / E[q][q]
+    sweepq_load_image<NB, STRICT>(img, opl, rinv);
     unsigned long long mword = 0ull;
     if (HAS_MASK) mword = a.mask[cc];
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -223,7 +234,6 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
         const int q = 4 * b + ri;
         acc[b] = (q < k) ? ((a.r2 != 0) ? a.r2 - acc[b] : -acc[b]) * (STRICT ? 1.0 : rinv[q]) : 0.0;
     }
-    __syncthreads(); // operand image complete
     // this lane's operand values: lane (kA, blk, iA) reads entry li = 4 kA + iA of every operand (all four blk groups the same)
     const f64x2 *opv = (const f64x2 *)opl + (4 * (lane >> 4) + (lane & 3));
     // pairs p = 0 .. NP - 1 of block B: entries 2 p, 2 p + 1 of fetch(B) -> set[2 p], set[2 p + 1]
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && (NB >= 15 || (STRICT 
 __host__ __device__ static inline size_t sweepqw_slot_doubles(int NB) { return (size_t)(2 * NB + 1) * 64 + 64; } // per lane: x, gradients, owed deltas; (act, sweeps) as ints
 __host__ __device__ static inline size_t sweepqw_lds_bytes(int KP, int NB, bool strict, int G)
 {
-    return ((size_t)16 * G * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 3 * sweepqw_slot_doubles(NB)) * 8 + 64;
+    return ((size_t)16 * G * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB + 3 * sweepqw_slot_doubles(NB)) * 8 + 64;
 }
 
 // sweepq_epilogue for a run-time number of columns (a multiple of 16)
@@ -474,21 +484,20 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 1) void sweep_scd_qw_kernel(const S
     const int SLOT = (int)sweepqw_slot_doubles(NB);
     double *xl = (double *)sq_smem;             // [16 G][XS]: x[column][coordinate], final values
     double *opl = xl + (size_t)16 * G * XS;     // [NB * NP * 32]: the operand image
-    double *hand = opl + NB * NP * 32;          // [3][SLOT]: slot w = state on its way from wavefront w + 1 to wavefront w
+    double *rinv = opl + NB * NP * 32;          // [4 NB]: 1 / E[q][q]
+    double *hand = rinv + 4 * NB;               // [3][SLOT]: slot w = state on its way from wavefront w + 1 to wavefront w
     int *ready = (int *)(hand + 3 * SLOT);      // [3]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ri = lane >> 4, c16 = lane & 15;
     const int k = a.k;
     const int col_wg = a.col0 + 16 * G * (int)blockIdx.x; // first column of the workgroup
 
-    for (int e = tid; e < NB * NP * 16; e += SWEEPQ_THREADS) ((f64x2 *)opl)[e] = ((const f64x2 *)img)[e];
     if constexpr (KP > 4 * NB) { // coordinates beyond the last block
         constexpr int REST = KP - 4 * NB;
         for (int e = tid; e < 16 * G * REST; e += SWEEPQ_THREADS) xl[(e / REST) * XS + 4 * NB + e % REST] = 0.0;
     }
     if (tid < 3) ready[tid] = 0;
-    __syncthreads(); // operand image complete, flags clear
-    const double *rinv = img + (size_t)NB * NP * 32;
+    sweepq_load_image<NB, STRICT>(img, opl, rinv); // (ends with a barrier: operand image complete, flags clear)
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
     const f64x2 *opv = (const f64x2 *)opl + (4 * (lane >> 4) + (lane & 3));
     auto fetch = [&](auto bc, double(&set)[2 * NP]) {

@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void factor16_kernel(const double *__restrict_
 __global__ __launch_bounds__(1024) void factor16_fold_kernel(const double *__restrict__ X, int ld, int ncols, int k, int KP, int plen,
                                                              unsigned *__restrict__ maxbits, int *__restrict__ exp_out, uint32_t *__restrict__ Y16,
                                                              unsigned *__restrict__ zero_word, const double *__restrict__ slabs, int nslabs,
-                                                             double *__restrict__ G)
+                                                             double *__restrict__ G, const SweepImg im)
 {
     const int nfold = KP * KP / 64;
     if ((int)blockIdx.x < nfold) {
-        gram_fold_body(slabs, nslabs, KP, G, blockIdx.x);
+        gram_fold_body(slabs, nslabs, KP, G, blockIdx.x, im); // (+ the operand image of this half-step's sweep: no pack launch)
         return;
     }
     const int e = split16_exponent(__uint_as_float(*maxbits));

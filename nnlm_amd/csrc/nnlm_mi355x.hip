@@ -976,7 +976,7 @@ static void launch_gram(nnlm_handle *h, const double *Y, int ld, int c_begin, in
     }
     const int KP = h->KP;
     // (16 wavefronts per 64 entries, every 16th slab each: 5 us where the one-thread-per-entry sum over ~80 slabs took 20-25)
-    gram_fold_kernel<<<KP * KP / 64, 1024, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw);
+    gram_fold_kernel<<<KP * KP / 64, 1024, 0, h->stream>>>(h->gslabs, nb, KP, h->Graw, SweepImg{});
     *nslabs = nb;
 }
 
@@ -1686,17 +1686,19 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (fastsw && sg_which == (which == 1 ? 0 : 1)) {
             {
                 ProfScope ps(h, P_GRAM, h->stream);
+                // (the fold of the Gram partial sums also writes the operand image of this half-step's sweep: no sweepq_pack_kernel launch)
+                SweepImg im;
+                im.img = h->sweepq_img, im.NB = (h->k + 3) / 4, im.NP = sweepq_np(im.NB, false), im.k = h->k, im.r0 = reg[0], im.r1 = reg[1];
                 if (h->fuse_err) { // (the fused error block needs more split copies: the general routine)
                     prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w, which == 0 && sg_other == 0);
-                    gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+                    gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw, im);
                 } else {
                     const double *Ym = (which == 1) ? h->W64 : h->H64;
                     const int ldm = (which == 1) ? h->npad : h->mpad, lim = (which == 1) ? h->n : h->m;
                     const size_t cnt = (size_t)h->KP * ldm;
                     factor16_fold_kernel<<<(unsigned)(h->KP * h->KP / 64 + (cnt + 1023) / 1024), 1024, 0, h->stream>>>(
-                        Ym, ldm, lim, h->k, h->KP, ldm, h->maxbits + 4 + h->sg_par, h->scal_exp + 1, h->Y16, smax_w, h->sg_slabs, h->sg_nslabs, h->Graw);
+                        Ym, ldm, lim, h->k, h->KP, ldm, h->maxbits + 4 + h->sg_par, h->scal_exp + 1, h->Y16, smax_w, h->sg_slabs, h->sg_nslabs, h->Graw, im);
                 }
-                sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(h->Graw, h->KP, h->k, reg[0], reg[1], (h->k + 3) / 4, h->sweepq_img, 0);
                 h->pack_ready = true;
             }
             {
@@ -1752,7 +1754,10 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     unsigned *gmb = nullptr;
     if (sg_strict && sg_which == ((which == 1) ? 0 : 1)) {
         ProfScope ps(h, P_GRAM, h->stream);
-        gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw);
+        SweepImg im; // (the fold also writes the sweep's operand image: no sweepq_pack_kernel launch)
+        im.img = h->sweepq_img, im.NB = (h->k + 3) / 4, im.NP = sweepq_np(im.NB, true), im.k = h->k, im.r0 = reg[0], im.r1 = reg[1];
+        gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw, im);
+        h->pack_ready = true;
         h->gshard_for = -1;
     } else if (!gram_cached) {
         h->gshard_for = -1;
