@@ -161,11 +161,15 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                 # v_mfma_f64_4x4x4 (16 of them per block of 4 coordinates and 16 columns), and 4x4x4 DGEMM issue is what bounds the kernel
                 # (one wavefront per SIMD: dependent-issue latency of the chain; two: the matrix pipe, which a second wavefront cannot overlap)
                 fl = inner * (cols / world) * k * (2 * k + 8)
-                knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else \
-                      "sweep_scd_q_kernel"  # (both modes since round 3: <.., STRICT = false> / <.., STRICT = true>)
+                # (both modes since round 3: <.., STRICT = false / true>; round 4: between one and two 16-column wavefronts per SIMD -- 1024 SIMDs --
+                #  the launch takes the persistent form sweep_scd_qw_kernel: 5 .. 7 column groups per CU shared by the wrap-around rule)
+                groups = -(-int(cols / world) // 16)
+                sweep_kernel = "sweep_scd_qw_kernel" if (1024 < groups and 5 <= -(-groups // 256) <= 7 and inner >= 4) else "sweep_scd_q_kernel"
+                knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
-                        "flops = inner*cols*k*(2k+8)")
+                        "flops = inner*cols*k*(2k+8); a SIMD runs one 16-column wavefront at full speed, so the floor of a launch is "
+                        "max(inner, ceil(groups per CU * inner / 4)) sweeps of ~2.16 us")
                 if cfg["na"]:
                     # + the per-column Grams over the complement rows, 2 k^2 flops per missing entry.  F32 mode: they run on the fp16 matrix
                     # cores as three split-fp16 products (a third of the dense fp16 peak per algorithmic flop); strict mode: fp64 MFMA.
@@ -182,7 +186,7 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                 # column (SURVEY 8d grants it no roofline); the fraction of the fp64 matrix peak is reported for scale, not as its bound.
                 # NA flow: per-column Grams on the matrix cores + the solver: "mfma".
                 classes[nm] = dict(bound=("mfma" if cfg["na"] else "latency"), kernel=f"{nm} ({knm})", work=fl, peak=pk, unit="TFLOP/s", scale=1e12,
-                                   pmc=(None if cfg["na"] else "sweep_scd_q_kernel"), note=note)
+                                   pmc=(None if cfg["na"] else sweep_kernel), note=note)
     else:
         for nm in ("sweep_h", "sweep_w"):
             if kern[nm]["ms_per_launch"]:

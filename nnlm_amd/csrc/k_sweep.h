@@ -59,7 +59,7 @@ struct SweepArgs {
     // k_sweep_q.h only (NULL elsewhere): what the NEXT half-step needs from the factor solved here, produced from the
     // final x image while it is still in LDS -- its Gram partial sums and max|x| (the scale of its split-fp16 copy)
     unsigned *maxbits = nullptr;      // atomicMax of the float bit pattern of max|x| over the solved columns
-    double *gram_slabs = nullptr;     // [workgroups][KP*KP]  Gram of each workgroup's 48 columns (upper tiles)
+    double *gram_slabs = nullptr;     // [workgroups][KP*KP]  Gram of each workgroup's 64 (persistent form: 16 G) columns (upper tiles)
 };
 
 // The SCD sweep's operand image (k_sweep_q.h), written straight from the fold: SweepImg describes it, sweepq_img_put() stores the
