@@ -793,15 +793,6 @@ static void launch_xprod16_m(nnlm_handle *h, const uint32_t *A16, int lda, int l
 {
     const int KP = 16 * NKQ;
     dim3 grid(p.tiles_x, p.S);
-    static const bool two_stage = getenv("NNLM_EXP_XPROD_NBUF2") != nullptr; // (round-4 probe, scripts/gpu_overlap_probe.py)
-    if (two_stage) {
-        const int lds2 = 2 * (XPROD_A_IMG_BYTES + KP * XPROD_ROWB);
-        set_dyn_lds((const void *)xprod16_tn_kernel<NKQ, 0, 2>, lds2, "xprod16_tn_kernel");
-        xprod16_tn_kernel<NKQ, 0, 2><<<grid, XPROD_THREADS, lds2, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
-                                                                               (Cx ? Cx : h->Cx) + p.col_off, ldc, slab_stride ? slab_stride : (size_t)KP * ldc,
-                                                                               p.stage_begin, p.stage_end, p.sps, h->scal_exp);
-        return;
-    }
     const int lds = xprod_tn_lds_bytes(KP);
     set_dyn_lds((const void *)xprod16_tn_kernel<NKQ>, lds, "xprod16_tn_kernel");
     xprod16_tn_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(A16 + (size_t)p.col_off * lda, lda, Y16 ? Y16 : h->Y16, ldy,
@@ -1223,6 +1214,7 @@ static bool colsolve_fast_ok(const nnlm_handle *h, int method)
 {
     return method == 1 && h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX;
 }
+
 static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_stride)
 {
     switch (h->NKQ) {

@@ -1,7 +1,7 @@
 """Probe (round 4): ONE kind of kernel per stream.  Handle X loops the cross-product phase of a sharded half-step (virtual rank 0 of 2,
 reduce form: Gram + split copy + half of the A-streaming cross product + slab fold), handle S loops the sweep phase (its 10000 of the
-20000 W columns, 50 sweeps) -- alone and concurrently.  NNLM_EXP_XPROD_NBUF2=1: the 96 KB two-stage cross product, which leaves room for
-a sweep workgroup on the same CU."""
+20000 W columns, 50 sweeps) -- alone and concurrently.  The 96 KB two-stage cross product of the measurement in DESIGN.md section 6 (xprod16_tn_kernel<NKQ, 0, 2>, which leaves
+room for a sweep workgroup on the same CU) was selected by a probe switch in launch_xprod16_m that has been removed again."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
