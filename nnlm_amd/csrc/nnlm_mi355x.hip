@@ -2545,8 +2545,8 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
     if ((unsigned)(i - 1) % trace != 0) { // src/nnmf.cpp:164 (unsigned arithmetic)
         double mse, kl, pen[6];
         long long raw = 0;
-        CHK(nnlm_errors(h, &mse, &kl, pen));
-        CHK(nnlm_take_sweeps(h, &raw, 1));
+        CHK(errors_launch(h, h->stream, true, 0, need_pen)); // (error sums and the sweep counter in one round trip)
+        CHK(errors_collect(h, &mse, &kl, pen, &raw));
         book(i, mse, kl, pen, raw);
     }
 
