@@ -1012,7 +1012,7 @@ static int sweep_lanes_per_column(int ncols)
 // fp64 mode: the reference's arithmetic (correctly rounded mu / G[q][q]).
 static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX; }
 
-// (the instantiations of sweep_scd_q_kernel / sweep_scd_qw_kernel -- 64 + 32 heavy ones -- live in translation units of their own,
+// (the instantiations of sweep_scd_q_kernel / sweep_scd_qw_kernel -- 64 + 64 heavy ones -- live in translation units of their own,
 //  tu_sweepq.hip / tu_sweepqw.hip, compiled next to this one: tu_sweepq.h)
 static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
 {
@@ -1031,8 +1031,7 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     int G = 0;
     if (ngroups > simds && a.max_iter >= 4) {
         G = (ngroups + h->cus - 1) / h->cus;
-        // (masked factors with that many columns stay on the plain form: the persistent one is not instantiated for them)
-        if (G < 5 || G > SWEEPQ_WRAP_MAXG || a.mask || sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, G) > (size_t)160 * 1024) G = 0;
+        if (G < 5 || G > SWEEPQ_WRAP_MAXG || sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, G) > (size_t)160 * 1024) G = 0;
     }
     if (G) nb = (ngroups + G - 1) / G;
     h->sweep_wgs = nb;

@@ -1,5 +1,5 @@
 // tu_sweepq.h -- launch entries of the SCD sweep kernels of k_sweep_q.h.  Their instantiations (one per block count NB = 1 .. 16,
-// mask, arithmetic mode) dominate the build, so they are compiled as translation units of their own, in parallel with
+// mask, arithmetic mode: 64 + 64) dominate the build, so they are compiled as translation units of their own, in parallel with
 // nnlm_mi355x.hip (nnlm_amd/build.py): tu_sweepq.hip (sweep_scd_q_kernel) and tu_sweepqw.hip (sweep_scd_qw_kernel, the persistent form).
 // Both return what hipFuncSetAttribute(MaxDynamicSharedMemorySize) said; the launch itself is checked by the caller (LAUNCHCHK).
 #pragma once
@@ -7,5 +7,5 @@
 
 // nb workgroups of 64 columns (four wavefronts of 16); img = the operand image written by sweepq_pack_kernel
 hipError_t nnlm_tu_sweep_q(const SweepArgs &a, const double *img, int nb, int NB, bool strict, hipStream_t st);
-// nb workgroups of G column groups of 16 (one workgroup per CU); unmasked factors only (a.mask == NULL)
+// nb workgroups of G column groups of 16 (one workgroup per CU)
 hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int NB, bool strict, int G, hipStream_t st);

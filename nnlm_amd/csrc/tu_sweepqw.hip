@@ -2,21 +2,21 @@
 #include "tu_sweepq.h"
 #include "k_sweep_q.h"
 
-template <int NT, int NB, bool S> static hipError_t launch_k(const SweepArgs &a, const double *img, int nb, int G, hipStream_t st)
+template <int NT, int NB, bool M, bool S> static hipError_t launch_k(const SweepArgs &a, const double *img, int nb, int G, hipStream_t st)
 {
     size_t lds = sweepqw_lds_bytes(16 * NT, NB, S, G);
     if (lds < (size_t)82 * 1024) lds = (size_t)82 * 1024; // (more than half a CU's LDS: one workgroup per CU, one wavefront per SIMD)
-    const hipError_t e = hipFuncSetAttribute((const void *)sweep_scd_qw_kernel<NT, NB, false, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    sweep_scd_qw_kernel<NT, NB, false, S><<<nb, SWEEPQ_THREADS, lds, st>>>(a, img, G);
+    const hipError_t e = hipFuncSetAttribute((const void *)sweep_scd_qw_kernel<NT, NB, M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    sweep_scd_qw_kernel<NT, NB, M, S><<<nb, SWEEPQ_THREADS, lds, st>>>(a, img, G);
     return e;
 }
 template <int NT, int NB> static hipError_t launch_m(const SweepArgs &a, const double *img, int nb, bool strict, int G, hipStream_t st)
 {
-    return strict ? launch_k<NT, NB, true>(a, img, nb, G, st) : launch_k<NT, NB, false>(a, img, nb, G, st);
+    if (strict) return a.mask ? launch_k<NT, NB, true, true>(a, img, nb, G, st) : launch_k<NT, NB, false, true>(a, img, nb, G, st);
+    return a.mask ? launch_k<NT, NB, true, false>(a, img, nb, G, st) : launch_k<NT, NB, false, false>(a, img, nb, G, st);
 }
 hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int NB, bool strict, int G, hipStream_t st)
 {
-    if (a.mask) return hipErrorInvalidValue; // (the caller keeps masked factors on the plain form)
     switch (NB) {
     case 1: return launch_m<1, 1>(a, img, nb, strict, G, st);
     case 2: return launch_m<1, 2>(a, img, nb, strict, G, st);
