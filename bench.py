@@ -63,12 +63,12 @@ CONFIGS = {
 
 def make_inputs(n, m, k, na):
     rng = np.random.default_rng(SEED)
-    A = rng.random((n, m))
+    A = np.asfortranarray(rng.random((n, m)))  # (column-major, as R holds it: the binding then passes it without a transposing copy)
     W0 = 0.01 * rng.random((n, k))
     H0 = 0.01 * rng.random((k, m))
     if na:
-        A = A.copy()
-        A.ravel()[np.random.default_rng(7).choice(n * m, n * m // 10, replace=False)] = np.nan
+        idx = np.random.default_rng(7).choice(n * m, n * m // 10, replace=False)  # (row-major linear indices, as in rounds 1-3)
+        A[np.unravel_index(idx, (n, m))] = np.nan
     return A, W0, H0
 
 

@@ -40,8 +40,16 @@ def report(name, **figs):
 
 def inputs():
     rng = np.random.default_rng(SEED)
-    A = rng.random((N, M))
+    A = np.asfortranarray(rng.random((N, M)))  # (column-major: passed to the library without a transposing copy)
     return A, 0.01 * rng.random((N, K)), 0.01 * rng.random((K, M))
+
+
+def punch_holes(A):
+    """10 % of the entries NaN, the positions bench.py uses (row-major linear indices from seed 7)."""
+    A = A.copy(order="F")
+    idx = np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)
+    A[np.unravel_index(idx, (N, M))] = np.nan
+    return A
 
 
 def test_config2_f32_twenty_iterations_drift_and_fused_error_traces():
@@ -137,8 +145,7 @@ def test_config3_full_size_one_iteration(name, method):
 def test_config5_full_size_one_iteration():
     """BASELINE configs[4]: 10 % missing entries + L1/L2 regularisation (update_with_missing path), F32 mode."""
     A, W0, H0 = inputs()
-    A = A.copy()
-    A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+    A = punch_holes(A)
     reg = [0.01, 0.0, 0.01]
     with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
         h.set_matrix(A)
@@ -167,8 +174,7 @@ def test_configs_3_and_5_full_size_drift_over_iterations(name, method, na, iters
     every iteration's error block is compared): the drift of the F32 mode against the oracle, measured and reported."""
     A, W0, H0 = inputs()
     if na:
-        A = A.copy()
-        A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+        A = punch_holes(A)
     reg = [0.01, 0.0, 0.01] if na else [0.0, 0.0, 0.0]
     inner = 50 if method < 3 else 1
     with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
@@ -247,8 +253,7 @@ def test_config5_strict_f64_full_size_one_iteration():
     """BASELINE configs[4] in the strict fp64 mode (na_gram_lds_kernel<double> + colsolve_strict_kernel + errors_kernel<double>
     with missing bits): one outer iteration at full size, per-column sweep counts exact."""
     A, W0, H0 = inputs()
-    A = A.copy()
-    A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+    A = punch_holes(A)
     reg = [0.01, 0.0, 0.01]
     with nnlm_amd.Handle(0, _lib.PREC_F64) as h:
         h.set_matrix(A)
@@ -374,8 +379,7 @@ def test_configs_3_and_5_full_size_eight_virtual_ranks(name, method, na):
     ends bit-identical and equal to the single-handle run (which the tests above hold against the oracle at this size)."""
     A, W0, H0 = inputs()
     if na:
-        A = A.copy()
-        A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
+        A = punch_holes(A)
     reg = [0.01, 0.0, 0.01] if na else [0.0, 0.0, 0.0]
     inner = 50 if method < 3 else 1
     with nnlm_amd.Handle(0, _lib.PREC_F32) as h1:
