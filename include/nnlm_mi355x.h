@@ -12,7 +12,8 @@
  *
  * Conventions (all taken from the reference):
  *   - every matrix is column-major (R / Armadillo), fp64 at the boundary;
- *   - logical masks are `int` arrays (R LGLSXP), non-zero = masked (entry is never updated);
+ *   - logical masks are `int` arrays (R LGLSXP), non-zero = masked (entry is never updated) -- NA_LOGICAL (INT_MIN) included:
+ *     the reference converts the matrix to arma::umat and tests `mask(k) > 0` (src/RcppExports.cpp:38-39, src/base_algorithms.cpp:21);
  *   - missing entries of A / y are any non-finite value (NA, NaN, +-Inf), src/nnmf.cpp:65-68;
  *   - method: 1 scd+mse, 2 lee+mse, 3 scd+mkl, 4 lee+mkl (R/misc.R:28-35);
  *   - alpha/beta: [L2, angle, L1] (src/nnmf.cpp:19-20).
@@ -110,8 +111,11 @@ void nnlm_destroy(nnlm_handle *h);
 const char *nnlm_last_error(const nnlm_handle *h); /* h may be NULL: error of the last failed nnlm_create / one-shot call */
 int nnlm_abi_version(void);
 
-/* Upload A (n x m, fp64, column-major).  One pass on the device converts to the resident layout,
- * finds the non-finite entries (src/nnmf.cpp:65-69) and sums the constant KL part (src/nnmf.cpp:70,73). */
+/* Upload A (n x m, fp64, column-major; never written).  One pass on the device converts to the resident layout,
+ * finds the non-finite entries -- NA, NaN, +Inf and -Inf alike are "missing" (src/nnmf.cpp:65-69) -- and sums the constant
+ * KL part (src/nnmf.cpp:70,73).  The matrix is streamed through pinned staging buffers filled by a few host threads.
+ * NNLM_PREC_F32 only: NNLM_ERR_UNSUPPORTED when A holds a finite entry beyond FLT_MAX or its largest entry is below 2^-100
+ * (the 4-byte resident copy cannot represent it; NNLM_PREC_F64 takes such a matrix, as the reference does). */
 int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m);
 /* Number of finite entries of A (N_non_missing, src/nnmf.cpp:51,69) and the any_missing flag. */
 int nnlm_matrix_info(nnlm_handle *h, double *n_non_missing, int *any_missing, double *kl_const);
