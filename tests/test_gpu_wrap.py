@@ -40,8 +40,7 @@ def _run(monkeypatch, cus, prec, A, k, W0, H0, Wm, Hm, reg, inner, tol, iters):
 
 @pytest.mark.parametrize("pname,prec,otol", [("f64", _lib.PREC_F64, 1e-9), ("f32", _lib.PREC_F32, 1e-4)])
 @pytest.mark.parametrize("cus,n,m", [(2, 150, 224), (3, 260, 330), (1, 70, 112)])  # G = 5 .. 7 each way (150 -> 5, 224 -> 7, 260 -> 6, 330 -> 7, 70 -> 5, 112 -> 7), ragged ends
-@pytest.mark.parametrize("k,masks,inner,itol", [(50, False, 50, 1e-9), (7, True, 9, 1e-9), (64, True, 6, 1e-2), (33, False, 50, 1e-3), (3, False, 4, -1.0),
-                                                 (57, True, 12, 1e-9)])
+@pytest.mark.parametrize("k,masks,inner,itol", [(50, False, 50, 1e-9), (7, True, 9, 1e-9), (64, True, 6, 1e-2), (33, False, 50, 1e-3)])
 def test_persistent_sweep_is_bit_identical_to_the_plain_form(monkeypatch, pname, prec, otol, cus, n, m, k, masks, inner, itol):
     rng = np.random.default_rng(1000 * k + n + cus)
     kk = min(k, n, m)
