@@ -38,5 +38,5 @@ for form, world in [("cols", 1)] + [(f, w) for f in ("cols", "reduce") for w in 
             res["W" if which == 0 else "H"] = {("half_step" if world == 1 else {1: "contract", 2: "sweep", 3: "unpack", 4: "next_sweep_with_gathered_gram"}[ph]): round(1e3 * min(v), 4) for ph, v in ts.items() if v}
         out[f"{form}_{world}" if world > 1 else "1"] = res
         print(form, world, json.dumps(res), flush=True)
-os.makedirs("gpurun_out/r03", exist_ok=True)
-json.dump(out, open("gpurun_out/r03/shard_times.json", "w"))
+os.makedirs("gpurun_out/r04", exist_ok=True)
+json.dump(out, open("gpurun_out/r04/shard_times.json", "w"))
