@@ -2,6 +2,7 @@
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, on N GPUs of one node.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # no WORLD_SIZE in the environment: spawns its N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -10,7 +11,8 @@ steps, the error block (src/nnmf.cpp:135-160).  Default workload = BASELINE.json
 sequential coordinate descent, dense A 20000 x 10000 = U(0,1) synthetic, explicit 0.01*U(0,1) init, R defaults
 inner.max.iter=50, inner.rel.tol=1e-9, trace=2, rel.tol=-1 (fixed work).  A, W, H are resident in HBM when the timed
 region starts.  N > 1: A replicated, every rank does the half-step of its 1/N of the columns, one RCCL all-gather per half-step
-(strong scaling; NNLM_SHARD_DENSE=reduce: contraction-sharded + all-reduce + all-gather).
+(strong scaling; `--form reduce`: contraction-sharded + all-reduce + all-gather; `--form both`, the default at N > 1: `value` is the
+column form and `forms` carries step time and per-phase times of BOTH in the one line).
 `--config 3` / `--config 5` time BASELINE.json configs[2] (KL + Lee) / configs[4] (10 % NA + L1/L2) the same way (second
 bench lines for profiles/; the driver's line is the default config 2).  `--protocol core` = SURVEY section 8d's P-core (no
 error block inside the timed iterations).
@@ -24,7 +26,9 @@ Prints ONE JSON line on rank 0 (see the task contract) with
   step                whole-step fractions: SURVEY section 8d's bytes per iteration / time against the HBM peak, it/s against
                       its ceiling,
   cpu_baseline        oracle/nnlm_ref.c (OpenMP) on this box's host cores over the SAME iteration window (it starts from the
-                      factors the GPU had after its warm-up), plus a single-thread figure (n.threads = 1 is R's default),
+                      factors the GPU had after its warm-up), plus one full iteration on ONE thread (n.threads = 1 is R's default),
+  call                (N = 1, default config) SURVEY 8d's call-level metric: n.iteration / wall time of ONE nnlm_c_nnmf() -- the .Call
+                      entry: handle, code object, allocations, upload of A, 200 iterations, download -- from a cold process, both modes,
   mse_check           GPU and CPU mse after the same number of iterations from the same state.
 """
 import argparse
@@ -107,9 +111,8 @@ def pmc_traffic(kernel, config=2, f64=False):
 
 
 def cpu_baseline(A, Ww, Hw, k, cfg, iters, trace):
-    """oracle/nnlm_ref.c from the warmed factors (the window the GPU's timed region covers), all host threads; plus the
-    single-thread cost of one iteration extrapolated from 1/32 of each half-step's columns (a full single-thread iteration
-    takes about a minute)."""
+    """oracle/nnlm_ref.c from the warmed factors (the window the GPU's timed region covers), all host threads; plus ONE whole
+    outer iteration (A.t(), both half-steps, error block) on one thread -- R's default n.threads = 1 -- measured, not extrapolated."""
     from oracle import ref
     ref.lib()
     cores = os.cpu_count() or 1
@@ -123,21 +126,17 @@ def cpu_baseline(A, Ww, Hw, k, cfg, iters, trace):
                       f"with oracle/nnlm_ref.c (C/OpenMP restatement with the reference's cost structure, hand-written loops "
                       f"instead of BLAS), n.threads = all {cores} host threads",
                seconds=dt, final_mse=float(r["mse_error"][-1]), average_epoch=float(np.sum(r["average_epoch"]) / max(iters, 1)))
-    frac = 32
-    mc, nc = max(m // frac, 1), max(n // frac, 1)
-    t0 = time.perf_counter()
-    ref.update(Hw[:, :mc].copy(), Ww.T.copy(), np.ascontiguousarray(A[:, :mc]), None, z, cfg["inner"], INNER_TOL, cfg["method"], n_threads=1)
-    th = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ref.update(Ww[:nc].T.copy(), Hw, np.ascontiguousarray(A[:nc].T), None, z, cfg["inner"], INNER_TOL, cfg["method"], n_threads=1)
-    tw = time.perf_counter() - t0
-    out["threads1"] = dict(value=1.0 / (m / mc * th + n / nc * tw), unit="iterations/s", cores=1,
-                           sample=f"one H half-step over the first {mc} of {m} columns ({th:.2f} s) and one W half-step over the first {nc} of {n} rows "
-                                  f"({tw:.2f} s) on ONE thread (R's default n.threads = 1), scaled to all columns; A.t() and the error block not included")
+    if os.environ.get("NNLM_BENCH_THREADS1", "1") == "1":
+        t0 = time.perf_counter()
+        r1 = ref.c_nnmf(A, k, Ww, Hw, None, None, z, z, 1, -1.0, 1, 0, False, cfg["inner"], INNER_TOL, cfg["method"], trace)
+        t1 = time.perf_counter() - t0
+        out["threads1"] = dict(value=1.0 / t1, unit="iterations/s", cores=1, seconds=t1, final_mse=float(r1["mse_error"][-1]),
+                               sample="ONE whole outer iteration of the same problem from the same state (A.t(), W half-step, H half-step, error block) "
+                                      "with oracle/nnlm_ref.c on one thread (R's default n.threads = 1): measured, not extrapolated")
     return out, r
 
 
-def analyse(cfg, config_id, kern, n, m, k, s, world):
+def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
     """Roofline blocks from the HIP-event scopes of one profiled run: (dominant class, secondary = the H half-step's cross product
     when it is not the dominant one, all classes, shares of kernel time).  s = bytes per stored element of A."""
     inner, method = cfg["inner"], cfg["method"]
@@ -163,8 +162,8 @@ def analyse(cfg, config_id, kern, n, m, k, s, world):
                 fl = inner * (cols / world) * k * (2 * k + 8)
                 # (both modes since round 3: <.., STRICT = false / true>; round 4: between one and two 16-column wavefronts per SIMD -- 1024 SIMDs --
                 #  the launch takes the persistent form sweep_scd_qw_kernel: 5 .. 7 column groups per CU shared by the wrap-around rule)
-                groups = -(-int(cols / world) // 16)
-                sweep_kernel = "sweep_scd_qw_kernel" if (1024 < groups and 5 <= -(-groups // 256) <= 7 and inner >= 4) else "sweep_scd_q_kernel"
+                # (which form the launch took is the library's decision -- device CU count, LDS limit: nnlm_get_info, recorded by the caller)
+                sweep_kernel = "sweep_scd_qw_kernel" if (sweep_forms or {}).get(nm) == 1 else "sweep_scd_q_kernel"
                 knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
@@ -240,6 +239,91 @@ def profile_scopes(h):
     return kern
 
 
+def sweep_forms_of(h):
+    """{"sweep_w": 0 | 1 | -1, "sweep_h": ...}: form of the handle's last SCD sweep launches (0 plain, 1 persistent; nnlm_get_info)."""
+    return {"sweep_w": int(h.get_info("sweep_form_w")), "sweep_h": int(h.get_info("sweep_form_h"))}
+
+
+def call_probe(precision, n, m, k, max_iter):
+    """(child process of `call_metric`) ONE nnlm_c_nnmf() from a cold process state, then a second one: wall seconds of each."""
+    from nnlm_amd import _lib
+    cfg = CONFIGS[2]
+    A, W0, H0 = make_inputs(n, m, k, False)
+    z = cfg["reg"]
+    res = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = _lib.c_nnmf(A, k, W0, H0, None, None, z, z, max_iter, -1.0, 1, 0, False, cfg["inner"], INNER_TOL, cfg["method"], cfg["trace"])
+        res.append(dict(wall_s=time.perf_counter() - t0, n_iteration=r["n_iteration"], final_mse=float(r["mse_error"][-1])))
+    print(json.dumps(dict(precision=precision, max_iter=max_iter, cold=res[0], warm=res[1])), flush=True)
+
+
+def call_metric(n, m, k, local_rank, max_iter=200):
+    """SURVEY section 8d's call-level metric (R/nnmf.R:176-183, what $run.time covers): n.iteration / wall seconds of ONE
+    nnlm_c_nnmf() -- create, code-object load, allocations, upload of A, `max_iter` iterations with R's trace = 2, download --
+    in a FRESH process per arithmetic mode (cold: nothing of the library has run in it), and of a second call in the same process."""
+    import subprocess
+    out = {}
+    for prec in ("f32", "f64"):
+        env = dict(os.environ, NNLM_PRECISION=prec, NNLM_DEVICE=str(local_rank))
+        for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(v, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--call-probe", prec, "--size", f"{n},{m},{k}", "--call-iters", str(max_iter)]
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[prec] = dict(error=f"rc {p.returncode}: {p.stderr.strip()[-300:]}")
+                continue
+            d = json.loads(line[-1])
+            for key in ("cold", "warm"):
+                d[key]["iterations_per_s"] = d[key]["n_iteration"] / d[key]["wall_s"]
+            out[prec] = dict(dtype=DTYPE_NAMES[prec], max_iter=max_iter, cold=d["cold"], warm=d["warm"])
+        except Exception as e:  # (never lose the headline over a secondary measurement)
+            out[prec] = dict(error=f"{type(e).__name__}: {e}")
+    out["note"] = ("wall time of one nnlm_c_nnmf() call (the .Call entry: handle + code object + allocations + upload of the fp64 matrix + "
+                   f"{max_iter} iterations at trace = 2, rel.tol = -1 + download), python ctypes wrapper included; cold = first call of a fresh "
+                   "process, warm = second call in the same process; f64 is the .Call default (NNLM_PRECISION unset)")
+    return out
+
+
+def self_launch(n_ranks):
+    """`bench.py --gpus N` without a launcher: spawn the N ranks (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    as torch.distributed.run would), relay rank 0's stdout -- the one JSON line -- and return the first non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
+    rc, out0 = 0, b""
+    live = list(range(n_ranks))
+    while live:  # a rank that dies takes the others with it (they would wait in a collective for ever)
+        for r in list(live):
+            try:
+                if r == 0:
+                    o, _ = procs[0].communicate(timeout=0.5)
+                    out0 += o or b""
+                else:
+                    procs[r].wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            live.remove(r)
+            if procs[r].returncode != 0 and rc == 0:
+                rc = procs[r].returncode
+                print(f"bench.py: rank {r} of {n_ranks} exited with {rc}; stopping the others", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def other_config(config_id, precision, n, m, k, local_rank, steps, warmup):
     """A short run of another configuration on the same device (N = 1): ms per step, dominant kernel class, its fraction."""
     import nnlm_amd
@@ -263,7 +347,8 @@ def other_config(config_id, precision, n, m, k, local_rank, steps, warmup):
         h.sync()
         kern = profile_scopes(h)
         h.profile_enable(False)
-    roof, _, blocks, shares = analyse(cfg, config_id, kern, n, m, k, 8 if precision == "f64" else 4, 1)
+        forms = sweep_forms_of(h)
+    roof, _, blocks, shares = analyse(cfg, config_id, kern, n, m, k, 8 if precision == "f64" else 4, 1, forms)
     return dict(workload=cfg["name"].format(n=n, m=m, k=k), dtype=DTYPE_NAMES[precision], steps=steps, warmup=warmup, trace=trace,
                 ms_per_step=1e3 * dt / steps, iterations_per_s=steps / dt, final_mse=float(r["mse_error"][-1]),
                 dominant=dict(kernel=roof["kernel"], bound=roof["bound"], frac=roof["frac"], ms_per_launch=roof["ms_per_launch"],
@@ -286,7 +371,20 @@ def main():
     ap.add_argument("--size", default=None, help="n,m,k override for quick experiments (reported in config)")
     ap.add_argument("--others", type=int, default=1, help="1: after the headline (N = 1, default config) also time strict-fp64 config 2 and fp32 configs 3 and 5 "
                                                           "for a few iterations each -> other_configs; 0: skip")
+    ap.add_argument("--form", default=os.environ.get("NNLM_SHARD_DENSE", "both"), choices=["cols", "reduce", "both"],
+                    help="N > 1, dense square loss: cols = column-sharded half-steps + one all-gather each (`value` of `both`), reduce = contraction-sharded "
+                         "+ one all-reduce of [G | C] + all-gather, both = time the two forms in one invocation -> forms")
+    ap.add_argument("--call", type=int, default=1, help="1: (N = 1, default config) also time one cold nnlm_c_nnmf() call per mode in a child process -> call")
+    ap.add_argument("--call-iters", type=int, default=200, help="max.iter of the call-level metric (SURVEY 8d: 200)")
+    ap.add_argument("--call-probe", default=None, choices=["f32", "f64"], help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.call_probe:  # child of call_metric(): nothing but the one-shot call
+        n_, m_, k_ = (int(v) for v in args.size.split(",")) if args.size else (N_, M_, K_)
+        call_probe(args.call_probe, n_, m_, k_, args.call_iters)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # plain `python bench.py --gpus N`: be the launcher
+        sys.exit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line, the JSON: whatever libraries print on the way (RCCL's version banner, gloo's connection notes --
     # C stdio and Python alike) goes to stderr until the line is ready
@@ -304,9 +402,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s), as the launcher set up", file=sys.stderr)
 
     import nnlm_amd
     from nnlm_amd import _lib
@@ -328,7 +424,7 @@ def main():
     if dist is not None:
         ids = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        h.comm_init(ids[0], rank, world)
+        h.comm_init(ids[0], rank, world, form=("reduce" if args.form == "reduce" else "cols"))
     t0 = time.perf_counter()
     h.set_matrix(A)
     upload_s = time.perf_counter() - t0
@@ -380,6 +476,37 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         phase_tot = [float(v) for v in tt]
     phases_ms = {nm: v / args.steps for nm, v in zip(SCOPES, phase_tot) if v > 0}
+    main_forms = sweep_forms_of(h)
+
+    # --form both (N > 1, dense square loss): the same steps once more in the all-reduce form north_star words -- one timed region and
+    # one profiled replay -- so that ONE line prices the [G | C] all-reduce against the all-gather-only default
+    forms = None
+    if dist is not None and args.form == "both" and cfg["method"] < 3 and not cfg["na"] and k <= 64:
+        forms = {"cols": dict(ms_per_step=1e3 * times[0] / args.steps, phases_ms=dict(phases_ms))}
+        h.comm_set_form("reduce")
+        run_steps(h, cfg, args.warmup, trace)
+        barrier()
+        t0 = time.perf_counter()
+        rr = run_steps(h, cfg, args.steps, trace)
+        barrier()
+        t_red = max_over_ranks(time.perf_counter() - t0)
+        h.profile_reset()
+        h.profile_enable(True)
+        barrier()
+        run_steps(h, cfg, args.steps, trace)
+        barrier()
+        kern_r = profile_scopes(h)
+        h.profile_enable(False)
+        tot_r = [kern_r[nm]["total_ms"] for nm in SCOPES]
+        import torch
+        tt = torch.tensor(tot_r, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        forms["reduce"] = dict(ms_per_step=1e3 * t_red / args.steps, final_mse=float(rr["mse_error"][-1]),
+                               phases_ms={nm: float(v) / args.steps for nm, v in zip(SCOPES, tt) if float(v) > 0})
+        forms["note"] = ("cols (`value`): a rank forms the cross product of ITS columns over the whole contraction, sweeps them, ONE all-gather per "
+                         "half-step; reduce (north_star's wording): contraction-sharded [Gram | cross product], ONE all-reduce, column-sharded "
+                         "sweep, ONE all-gather; same steps, the reduce region follows the cols regions from the factors they left")
+        h.comm_set_form("cols")
 
     # GPU mse after `cpu_iters` iterations from the warmed state (what the CPU sample reproduces)
     gpu_check = None
@@ -400,7 +527,7 @@ def main():
 
     s = 8 if args.precision == "f64" else 4
     inner, method = cfg["inner"], cfg["method"]
-    roofline, secondary, all_blocks, shares = analyse(cfg, args.config, kern, n, m, k, s, world)
+    roofline, secondary, all_blocks, shares = analyse(cfg, args.config, kern, n, m, k, s, world, main_forms)
 
     # whole step against SURVEY 8d's per-iteration figures (config 2): bytes A twice + factors, +A once on trace iterations
     ms_step = 1e3 * elapsed / args.steps
@@ -429,6 +556,10 @@ def main():
                 others[key] = other_config(cid, pr, n, m, k, local_rank, st, wu)
             except Exception as e:  # (never lose the headline over a secondary measurement)
                 others[key] = dict(error=f"{type(e).__name__}: {e}")
+    call = None
+    if args.call and world == 1 and not force_comm and args.config == 2 and args.precision == "f32" and args.protocol == "default":
+        del A  # (the child processes generate their own copy: 1.6 GB each way)
+        call = call_metric(n, m, k, local_rank, args.call_iters)
     out = {
         "metric": "nnmf iterations/sec + final MSE, dense A 20000x10000 k=50, 1/2/4/8 GPU",
         "value": args.steps / elapsed,
@@ -450,7 +581,7 @@ def main():
                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation folded into fp64 every 256 elements; Gram/mu/sweeps fp64; "
                              "KL solvers fp32 state" if s == 4 else "all fp64 (v_mfma_f64_16x16x4_f64, v_mfma_f64_4x4x4)"),
                    "parallelism": ((f"contraction sharded x{world} + 1 RCCL all-reduce, sweep sharded by columns + 1 all-gather, per half-step"
-                                    if os.environ.get("NNLM_SHARD_DENSE", "") == "reduce" and method < 3 and not cfg["na"] else
+                                    if args.form == "reduce" and method < 3 and not cfg["na"] else
                                     f"columns sharded x{world} (cross product, Gram, sweep of a rank's columns) + 1 RCCL all-gather per half-step")
                                    if (world > 1 or force_comm) else "1 GPU")},
         "repeats": {"ms_per_step": ms_all, "min": min(ms_all), "median": float(np.median(ms_all)), "max": max(ms_all),
@@ -459,6 +590,8 @@ def main():
         "roofline_secondary": secondary,
         "roofline_all": all_blocks,
         "other_configs": others,
+        "forms": forms,
+        "call": call,
         "step": step,
         "cpu_baseline": cpu,
         "mse_check": mse_check,

@@ -160,18 +160,23 @@ int nnlm_profile_reset(nnlm_handle *h);
  * solved is the unit: per half-step a rank forms the cross product of ITS 1/N of the columns over the
  * whole contraction (1/N of A from HBM), the Gram of the fixed factor (dense: one shared k x k Gram,
  * replicated; missing values: one per column), solves its columns into a packed slab, and ONE
- * ncclAllGather returns the updated factor to every rank.  Dense square loss also has the form
- * north_star words (environment NNLM_SHARD_DENSE=reduce, read by nnlm_comm_init): each rank contracts
+ * ncclAllGather returns the updated factor to every rank (NNLM_FORM_COLS, the default).  Dense square loss also
+ * has the form north_star words (NNLM_FORM_REDUCE, chosen with nnlm_comm_set_form): each rank contracts
  * its slab of rows (H half-step) / columns (W half-step), ONE ncclAllReduce sums the partial
  * [Gram | cross-product] buffer, then the column-sharded sweep and the all-gather -- same HBM bytes and
  * kernel time per rank (profiles/r02_shard_times.json), one more collective of (KP^2 + KP cols) doubles.
  * Error block: each rank reduces its share of A, two doubles are all-reduced.
  * ---------------------------------------------------------------------------------------- */
 #define NNLM_COMM_ID_BYTES 128
+#define NNLM_FORM_COLS 0   /* column-sharded half-steps, one all-gather each (every method) */
+#define NNLM_FORM_REDUCE 1 /* dense square loss, rank <= 64: contraction-sharded [G | C] + all-reduce, then sweep + all-gather */
 int nnlm_comm_unique_id(char id[NNLM_COMM_ID_BYTES]); /* rank 0 creates, the host layer broadcasts */
 int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES], int rank, int nranks);
 /* id == NULL makes a "virtual rank": the handle only computes rank's slab of an nranks-way split and leaves the
  * partial sums un-reduced (used with nnlm_debug_partial to test the shard arithmetic on one device). */
+/* Form of the dense square-loss half-step across ranks (NNLM_FORM_*); nnlm_comm_init resets it to NNLM_FORM_COLS.  The other
+ * half-steps (missing values, KL, rank > 64) are column-sharded whatever is set here. */
+int nnlm_comm_set_form(nnlm_handle *h, int form);
 int nnlm_comm_info(nnlm_handle *h, int *rank, int *nranks);
 /* Contraction range [begin, end) owned by `rank` of `nranks`: rows i of A for the H half-step (which = 1), columns j
  * for the W half-step (which = 0).  Pure function of the sizes (no device needed). */
@@ -190,6 +195,13 @@ int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out);
 int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const double reg[3], unsigned inner_max_iter,
                      double inner_rel_tol, int method);
 int nnlm_debug_exchange(nnlm_handle **handles, int nranks, int which, int stage);
+/* Test hook: handles created from now on plan their launches as if the device had `cus` compute units (0 = the device's own
+ * count) -- small problems then take the launch forms large ones take on the real device (persistent SCD sweep). */
+int nnlm_debug_set_cus(int cus);
+/* Facts about the handle's last launches, for bench.py's kernel attribution: key = "cus" (compute units the launch policy
+ * counts), "sweep_form_w" / "sweep_form_h" (SCD sweep of the last W / H half-step: 0 plain sweep_scd_q_kernel, 1 persistent
+ * sweep_scd_qw_kernel, -1 none yet), "sweep_groups_w" / "sweep_groups_h" (column groups per workgroup of that launch). */
+int nnlm_get_info(nnlm_handle *h, const char *key, double *value);
 
 #ifdef __cplusplus
 }

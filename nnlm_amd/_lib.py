@@ -18,6 +18,9 @@ NNLM_OK = 0
 PREC_F32 = 0
 PREC_F64 = 1
 COMM_ID_BYTES = 128
+FORM_COLS = 0    # column-sharded half-steps, one all-gather each (default)
+FORM_REDUCE = 1  # dense square loss: contraction-sharded [G | C] + all-reduce, then sweep + all-gather
+FORMS = {"cols": FORM_COLS, "reduce": FORM_REDUCE}
 
 # every symbol include/nnlm_mi355x.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -26,6 +29,7 @@ EXPORTS = [
     "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
     "nnlm_shard_range", "nnlm_shard_cols", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
+    "nnlm_comm_set_form", "nnlm_debug_set_cus", "nnlm_get_info",
 ]
 
 
@@ -117,6 +121,12 @@ def load():
     lib.nnlm_debug_phase.argtypes = [vp, C.c_int, C.c_int, dp, C.c_uint, C.c_double, C.c_int]
     lib.nnlm_debug_exchange.restype = C.c_int
     lib.nnlm_debug_exchange.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
+    lib.nnlm_comm_set_form.restype = C.c_int
+    lib.nnlm_comm_set_form.argtypes = [vp, C.c_int]
+    lib.nnlm_debug_set_cus.restype = C.c_int
+    lib.nnlm_debug_set_cus.argtypes = [C.c_int]
+    lib.nnlm_get_info.restype = C.c_int
+    lib.nnlm_get_info.argtypes = [vp, C.c_char_p, dp]
     _lib = lib
     return lib
 
@@ -332,10 +342,21 @@ class Handle:
         self._ck(self._lib.nnlm_profile_get(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, int(cnt.value)
 
-    def comm_init(self, unique_id, rank: int, nranks: int):
-        """unique_id=None -> virtual rank (no communicator; partial sums stay un-reduced)."""
+    def comm_init(self, unique_id, rank: int, nranks: int, form="cols"):
+        """unique_id=None -> virtual rank (no communicator; partial sums stay un-reduced).  form: "cols" (column-sharded half-steps,
+        one all-gather each) or "reduce" (dense square loss: contraction-sharded + all-reduce, then sweep + all-gather)."""
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES) if unique_id is not None else None
         self._ck(self._lib.nnlm_comm_init(self._h, buf, int(rank), int(nranks)))
+        self.comm_set_form(form)
+
+    def comm_set_form(self, form):
+        self._ck(self._lib.nnlm_comm_set_form(self._h, FORMS[form] if isinstance(form, str) else int(form)))
+
+    def get_info(self, key):
+        """cus, sweep_form_w / sweep_form_h (0 plain, 1 persistent, -1 none yet), sweep_groups_w / sweep_groups_h."""
+        v = C.c_double(0)
+        self._ck(self._lib.nnlm_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def debug_phase(self, which, phase, reg, inner_max_iter, inner_rel_tol, method):
         r = _vec3(reg)
@@ -372,6 +393,11 @@ def debug_exchange(handles, which, stage):
     """Host stand-in for ncclAllReduce (stage 1) / ncclAllGather (stage 2) between virtual ranks (test hook)."""
     arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
     _check(load().nnlm_debug_exchange(arr, len(handles), int(which), int(stage)))
+
+
+def debug_set_cus(cus: int):
+    """Test hook: handles created from now on plan their launches for `cus` compute units (0 = the device's own count)."""
+    _check(load().nnlm_debug_set_cus(int(cus)))
 
 
 def comm_unique_id() -> bytes:

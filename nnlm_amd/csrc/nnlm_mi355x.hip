@@ -52,6 +52,9 @@ struct nnlm_handle {
     int device = 0;
     int cus = 256;              // compute units of the device (sweep launch policy: one wavefront of the SCD sweep per SIMD, 4 SIMDs per CU)
     int sweep_wgs = 0;          // workgroups of the last sweep_scd_q(w)_kernel launch = Gram partial-sum slabs it left behind
+    int cur_which = 1;          // the half-step in progress (0: W, 1: H)
+    int sweep_form[2] = {-1, -1}, sweep_groups[2] = {0, 0}; // per half-step (0: W, 1: H): form of its last SCD sweep launch (0 plain, 1 persistent) and
+                                                             // column groups per workgroup (nnlm_get_info)
     int prec = NNLM_PREC_F32;
     hipStream_t stream = nullptr;   // main: cross products, solvers
     hipStream_t stream_e = nullptr; // error block, concurrent with the (speculative) next W half-step
@@ -145,6 +148,13 @@ struct nnlm_handle {
     long long prof_n[P_COUNT] = {0};
 };
 
+// Dynamic LDS beyond 64 KB must be granted per kernel.  The launch helpers are void: a refusal is remembered here and reported by the
+// next LAUNCHCHK (every half-step / error block ends with one), together with whatever the launch itself then raised.  The latch is
+// per thread, not per handle: fail() and every public entry that launches clear it, so a refusal never outlives the call it
+// happened in and is never reported against another handle's launch.
+static thread_local hipError_t g_attr_err = hipSuccess;
+static thread_local const char *g_attr_what = "";
+
 static int fail(nnlm_handle *h, int code, const char *fmt, ...)
 {
     char buf[512];
@@ -154,6 +164,7 @@ static int fail(nnlm_handle *h, int code, const char *fmt, ...)
     va_end(ap);
     g_last_error = buf;
     if (h) h->err = buf;
+    g_attr_err = hipSuccess; // (a refused attribute latched on the way here belongs to this failure, not to a later launch)
     return code;
 }
 
@@ -163,10 +174,6 @@ static int fail(nnlm_handle *h, int code, const char *fmt, ...)
         if (e__ != hipSuccess) return fail(h, NNLM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
-// Dynamic LDS beyond 64 KB must be granted per kernel.  The launch helpers are void: a refusal is remembered here and reported by the
-// next LAUNCHCHK (every half-step / error block ends with one), together with whatever the launch itself then raised.
-static thread_local hipError_t g_attr_err = hipSuccess;
-static thread_local const char *g_attr_what = "";
 static inline void set_dyn_lds(const void *fn, int lds, const char *what)
 {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -283,6 +290,15 @@ extern "C" unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace)
     return (unsigned)std::ceil((double)max_iter / (double)trace) + 1; // src/nnmf.cpp:53-54
 }
 
+static int g_debug_cus = 0; // nnlm_debug_set_cus: compute units the launch policies of new handles count (0 = the device's)
+
+extern "C" int nnlm_debug_set_cus(int cus)
+{
+    if (cus < 0) return fail(nullptr, NNLM_ERR_ARG, "nnlm_debug_set_cus: %d", cus);
+    g_debug_cus = cus;
+    return NNLM_OK;
+}
+
 extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
 {
     if (!out) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: out is NULL");
@@ -302,8 +318,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     h->device = device;
     h->prec = precision;
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("NNLM_DEBUG_CUS")) // test hook: pretend the device has this many CUs (the sweep's launch policy at small sizes)
-        if (atoi(e) > 0) h->cus = atoi(e);
+    if (g_debug_cus > 0) h->cus = g_debug_cus; // test hook (nnlm_debug_set_cus): the sweep's launch policy at small sizes
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_hdone, hipEventDisableTiming) != hipSuccess ||
@@ -498,14 +513,24 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
             memcpy(dst, src, bytes);
             return;
         }
+        // (no exception may cross the C ABI: a std::thread that cannot be created -- thread limit of a container -- or a vector that
+        //  cannot grow leaves its piece, and every piece after it, to a plain memcpy on this thread, and the mode is kept off from then on)
         std::vector<std::thread> th;
         const size_t per = ((bytes / nthreads) + 4095) & ~(size_t)4095;
-        for (unsigned t = 0; t < nthreads; t++) {
-            const size_t o = (size_t)t * per;
-            if (o >= bytes) break;
-            const size_t len = (bytes - o < per) ? bytes - o : per;
-            th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, len); });
+        size_t started = 0; // bytes handed to worker threads
+        try {
+            th.reserve(nthreads);
+            for (unsigned t = 0; t < nthreads; t++) {
+                const size_t o = (size_t)t * per;
+                if (o >= bytes) break;
+                const size_t len = (bytes - o < per) ? bytes - o : per;
+                th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, len); });
+                started = o + len;
+            }
+        } catch (...) {
+            nthreads = 1;
         }
+        if (started < bytes) memcpy((char *)dst + started, (const char *)src + started, bytes - started);
         for (auto &x : th) x.join();
     };
     double cnt = 0.0, klc = 0.0, over = 0.0;
@@ -1097,6 +1122,8 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     }
     if (G) nb = (ngroups + G - 1) / G;
     h->sweep_wgs = nb;
+    h->sweep_form[h->cur_which] = G ? 1 : 0;
+    h->sweep_groups[h->cur_which] = G ? G : 4;
     const bool strict = h->prec == NNLM_PREC_F64;
     const hipError_t ea = G ? nnlm_tu_sweep_qw(a, h->sweepq_img, nb, NB, strict, G, h->stream) : nnlm_tu_sweep_q(a, h->sweepq_img, nb, NB, strict, h->stream);
     if (ea != hipSuccess && g_attr_err == hipSuccess) {
@@ -1670,13 +1697,14 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "half_step: matrix and factors must be set first");
     if (method < 1 || method > 4) return fail(h, NNLM_ERR_ARG, "method must be 1..4 (got %d)", method);
     HIPCHK(h, hipSetDevice(h->device));
+    g_attr_err = hipSuccess; // (a refusal latched by an earlier call on this thread that returned before its LAUNCHCHK is not this call's)
     const int sg_which = h->sg_which; // what the previous sweep left behind (any half-step rewrites a factor: reset first)
     const int sg_other = h->sg_other;
     h->sg_prev = sg_which;
     h->sg_which = h->sg_other = -1;
     h->sg_request = false;
     if (generic_rank(h) && h->sharded && method < 3 && !h->any_missing && !h->dense_cols)
-        return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d across GPUs: only the column-sharded form (unset NNLM_SHARD_DENSE=reduce)", NNLM_KQ_MAX);
+        return fail(h, NNLM_ERR_UNSUPPORTED, "rank > %d across GPUs: only the column-sharded form (nnlm_comm_set_form(h, NNLM_FORM_COLS))", NNLM_KQ_MAX);
     if (partial_only) phase = PH_A;
     if (method >= 3) return half_step_kl(h, which, reg, inner_max_iter, inner_rel_tol, method, speculative, phase);
     // Missing values across GPUs: every column has a Gram of its own, so the column is the unit: a rank forms the
@@ -1686,7 +1714,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     // all-reduce, column-sharded sweep, one all-gather.  "cols": the column-sharded form of the NA / KL paths -- a rank forms the cross
     // product of ITS columns over the whole contraction (it holds all of A and, after the previous all-gather, all of the fixed
     // factor), the full Gram of the fixed factor (2 k^2 p flops, replicated), sweeps its columns, ONE all-gather.  Same HBM bytes per
-    // rank (1/N of A either way), no all-reduce of the (KP^2 + KP cols) doubles: NNLM_SHARD_DENSE=reduce|cols (default cols).
+    // rank (1/N of A either way), no all-reduce of the (KP^2 + KP cols) doubles: nnlm_comm_set_form, NNLM_FORM_COLS (default) | NNLM_FORM_REDUCE.
     // (read when the communicator is set up: nnlm_comm_init)
     const bool colshard = h->sharded && (h->any_missing || h->dense_cols);
     if (colshard && phase == PH_A) return NNLM_OK;
@@ -1950,6 +1978,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
                            int nslabs, bool speculative, int phase, bool colshard)
 {
     const int ncols = (which == 1) ? h->m : h->n;
+    h->cur_which = which;
     // dense SCD in the column form: the Gram partial sums of this rank's columns travel with its slab (shard_gram_sum_kernel)
     // (+ one double: the rank's max|x|, so that the unpack can write the split-fp16 copy of the factor as well)
     h->pack_tail = (h->sharded && colshard && method == 1 && !h->any_missing && !generic_rank(h)) ? (size_t)h->KP * h->KP + 1 : 0;
@@ -2370,10 +2399,7 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     invalidate_factor_caches(h); // (what an unpack left behind belongs to the previous communicator's exchange)
     h->pack_tail = 0;
     h->sharded = nranks > 1 || (id != nullptr); // a real 1-rank communicator runs the sharded path on one GPU (tests)
-    {
-        const char *form = getenv("NNLM_SHARD_DENSE"); // "reduce": contraction-sharded + all-reduce; default "cols": column-sharded, all-gather only
-        h->dense_cols = !(form && strcmp(form, "reduce") == 0);
-    }
+    h->dense_cols = true;                        // NNLM_FORM_COLS; nnlm_comm_set_form chooses the all-reduce form
     if (!id) return NNLM_OK;
     int rc = rccl_load();
     if (rc != NNLM_OK) return rc;
@@ -2383,6 +2409,32 @@ extern "C" int nnlm_comm_init(nnlm_handle *h, const char id[NNLM_COMM_ID_BYTES],
     ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, u, rank);
     if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     h->comm = comm;
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_comm_set_form(nnlm_handle *h, int form)
+{
+    if (!h) return fail(nullptr, NNLM_ERR_ARG, "nnlm_comm_set_form: handle is NULL");
+    if (form != NNLM_FORM_COLS && form != NNLM_FORM_REDUCE) return fail(h, NNLM_ERR_ARG, "nnlm_comm_set_form: unknown form %d", form);
+    if (h->dense_cols != (form == NNLM_FORM_COLS)) {
+        HIPCHK(h, hipSetDevice(h->device));
+        sync_all(h);
+        invalidate_factor_caches(h); // (Gram, max and split copy an unpack left behind belong to the other form's exchange)
+        h->pack_tail = 0;
+        h->dense_cols = form == NNLM_FORM_COLS;
+    }
+    return NNLM_OK;
+}
+
+extern "C" int nnlm_get_info(nnlm_handle *h, const char *key, double *value)
+{
+    if (!h || !key || !value) return fail(h, NNLM_ERR_ARG, "nnlm_get_info: NULL argument");
+    if (strcmp(key, "cus") == 0) *value = h->cus;
+    else if (strcmp(key, "sweep_form_w") == 0) *value = h->sweep_form[0];
+    else if (strcmp(key, "sweep_form_h") == 0) *value = h->sweep_form[1];
+    else if (strcmp(key, "sweep_groups_w") == 0) *value = h->sweep_groups[0];
+    else if (strcmp(key, "sweep_groups_h") == 0) *value = h->sweep_groups[1];
+    else return fail(h, NNLM_ERR_ARG, "nnlm_get_info: unknown key '%s'", key);
     return NNLM_OK;
 }
 

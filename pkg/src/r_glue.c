@@ -39,8 +39,10 @@ static void raise_interrupt(void)
     Rf_eval(call, R_BaseEnv);
     arg = PROTECT(Rf_mkString("abort"));
     call = PROTECT(Rf_lang2(Rf_install("invokeRestart"), arg));
-    Rf_eval(call, R_BaseEnv); /* does not return */
+    Rf_eval(call, R_BaseEnv); /* does not return where an "abort" restart is on the stack (every R front-end's top level) */
     UNPROTECT(5);
+    /* an embedded front-end without that restart: never hand a NULL result back for an interrupted call */
+    Rf_error("nnmf: interrupted by the user");
 }
 
 /* ---- callbacks = the R API points the reference touches (include/nnlm_mi355x.h nnlm_callbacks) ---------------- */

@@ -5,7 +5,6 @@ room for a sweep workgroup on the same CU) was selected by a probe switch in lau
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["NNLM_SHARD_DENSE"] = "reduce"
 import nnlm_amd
 from nnlm_amd import _lib
 
@@ -16,7 +15,7 @@ W0, H0 = 0.01 * rng.random((n, k)), 0.01 * rng.random((k, m))
 z = [0.0, 0.0, 0.0]
 hs = [nnlm_amd.Handle(0, _lib.PREC_F32) for _ in range(2)]
 for h in hs:
-    h.comm_init(None, 0, 2)
+    h.comm_init(None, 0, 2, form="reduce")
     h.set_matrix(A)
     h.set_factors(k, W0, H0)
     h.debug_phase(0, 1, z, 50, -1.0, 1)   # partial [G | C] of the W half-step in h->red: finite operands for the sweep phase

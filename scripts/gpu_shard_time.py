@@ -12,10 +12,9 @@ A = rng.random((n, m)); W0 = 0.01 * rng.random((n, k)); H0 = 0.01 * rng.random((
 z = [0.0, 0.0, 0.0]
 out = {}
 for form, world in [("cols", 1)] + [(f, w) for f in ("cols", "reduce") for w in (2, 4, 8)]:
-    os.environ["NNLM_SHARD_DENSE"] = form  # (read by nnlm_comm_init)
     with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
         if world > 1:
-            h.comm_init(None, world - 1, world)  # the last rank (ragged shard)
+            h.comm_init(None, world - 1, world, form=form)  # the last rank (ragged shard)
         h.set_matrix(A); h.set_factors(k, W0, H0)
         res = {}
         for which in (0, 1):

@@ -1,7 +1,7 @@
 """Worker for tests/test_dist_cpu.py: one rank of the SHIPPED multi-GPU exchange on CPU (gloo), driven by the product's own
 partition functions exported through the C ABI (nnlm_shard_range, nnlm_shard_cols; no GPU needed for those).
 
-Dense square-loss half-step, form "reduce" (NNLM_SHARD_DENSE=reduce; nnlm_mi355x.hip half_step / half_step_solve):
+Dense square-loss half-step, form "reduce" (nnlm_comm_set_form(NNLM_FORM_REDUCE); nnlm_mi355x.hip half_step / half_step_solve):
     1. every rank contracts ITS slab of the contraction (nnlm_shard_range) into one buffer [G (k x k) | C (k x cols)];
     2. ONE all_reduce(sum) of that buffer                                       (ncclAllReduce);
     3. every rank solves ITS columns [col0, col1) (nnlm_shard_cols) into a packed slab [k][cpr], zero padded;

@@ -2,7 +2,7 @@
 
 GPU side (nnlm_amd/csrc/nnlm_mi355x.hip half_step / half_step_solve / half_step_kl), two forms.  Column-sharded (default for
 everything: dense, missing values, KL): a rank does all the work of ITS columns over the whole contraction into a packed [k][cpr]
-slab -> ONE ncclAllGather -> unpack.  "reduce" (dense square loss with NNLM_SHARD_DENSE=reduce, north_star's wording):
+slab -> ONE ncclAllGather -> unpack.  "reduce" (dense square loss with nnlm_comm_set_form(NNLM_FORM_REDUCE), north_star's wording):
 contraction-sharded [Gram | cross-product] partials -> ONE ncclAllReduce -> column-sharded solve -> ONE ncclAllGather -> unpack.  tests/dist_worker.py runs exactly that exchange with torch.distributed/gloo, taking every range from the product's own
 partition functions (nnlm_shard_range, nnlm_shard_cols through the C ABI); the results must equal the unsharded oracle."""
 import os

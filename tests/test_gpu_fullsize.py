@@ -304,7 +304,7 @@ def _virtual_rank_iterations(A, W0, H0, prec, world, iters, reg, inner, method, 
     hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
     try:
         for rk, h in enumerate(hs):
-            h.comm_init(None, rk, world)
+            h.comm_init(None, rk, world, form="reduce" if reduce_form else "cols")
             h.set_matrix(A)
             h.set_factors(K, W0, H0)
         for _ in range(iters):
@@ -336,10 +336,6 @@ def test_config4_full_size_eight_virtual_ranks(monkeypatch, pname, prec, form):
     plans, cpr = 2560 / 1280 with the last rank's short slab (2080 / 1040 columns), the Gram that travels with the factor,
     shard_unpack at 313 / 157 workgroups per rank.  All ranks must end bit-identical, equal to the single-handle run up to the
     summation order of the split, and equal to the oracle's c_nnmf; sweep counts exact in the strict mode."""
-    if form == "reduce":
-        monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
-    else:
-        monkeypatch.delenv("NNLM_SHARD_DENSE", raising=False)
     A, W0, H0 = inputs()
     z = [0.0, 0.0, 0.0]
     with nnlm_amd.Handle(0, prec) as h1:

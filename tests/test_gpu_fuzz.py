@@ -184,10 +184,6 @@ def test_random_virtual_rank_runs(monkeypatch, seed):
     method = 1 + (seed // 4) % 4
     na = (seed // 2) % 3 == 1
     reduce_form = (seed % 2 == 1) and method <= 2 and not na
-    if reduce_form:
-        monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
-    else:
-        monkeypatch.delenv("NNLM_SHARD_DENSE", raising=False)
     Wp, Hp = rng.random((n, k + 2)) ** 2 + 0.05, rng.random((k + 2, m)) ** 2 + 0.05
     A = Wp @ Hp / (k + 2) * 4 + 0.02 * rng.random((n, m)) + 0.01
     if na:
@@ -214,7 +210,7 @@ def test_random_virtual_rank_runs(monkeypatch, seed):
         hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
         try:
             for rk, h in enumerate(hs):
-                h.comm_init(None, rk, world)
+                h.comm_init(None, rk, world, form="reduce" if reduce_form else "cols")
                 h.set_matrix(A)
                 h.set_factors(k, W0, H0, Wm, Hm)
             for _ in range(2):

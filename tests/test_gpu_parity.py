@@ -346,9 +346,8 @@ def test_config2_full_size_one_iteration_vs_oracle_and_properties():
 @pytest.mark.parametrize("pname,prec,tol", PRECS)
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_virtual_rank_partials_sum_to_the_unsharded_buffer(monkeypatch, pname, prec, tol, world):
-    """(The all-reduce form of the dense half-step, NNLM_SHARD_DENSE=reduce.)  Each virtual rank computes only its slab's [Gram | cross-product]; their sum (what ncclAllReduce forms) equals
+    """(The all-reduce form of the dense half-step, nnlm_comm_set_form(NNLM_FORM_REDUCE).)  Each virtual rank computes only its slab's [Gram | cross-product]; their sum (what ncclAllReduce forms) equals
     the single-rank buffer, and the numpy Gram/cross-product of the slab nnlm_shard_range() reports."""
-    monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")  # (read by nnlm_comm_init)
     rng = np.random.default_rng(world)
     n, m, k = 700, 300, 11
     A = rng.random((n, m))
@@ -366,7 +365,7 @@ def test_virtual_rank_partials_sum_to_the_unsharded_buffer(monkeypatch, pname, p
             with nnlm_amd.Handle(0, prec) as h:
                 h.set_matrix(A)
                 h.set_factors(k, W0, H0)
-                h.comm_init(None, rk, world)
+                h.comm_init(None, rk, world, form="reduce")
                 assert h.comm_info() == (rk, world)
                 G, Cp = h.debug_partial(which)
             b, e = _lib.shard_range(n, m, prec, which, rk, world)
@@ -384,7 +383,6 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(monkeypatch, pname,
     ncclAllGather and unpack.  With one rank every
     collective is the identity, so the result must be bit-identical to the plain path in the strict mode (same reduction
     orders) and equal to rounding in the f32 mode."""
-    monkeypatch.setenv("NNLM_SHARD_DENSE", form)
     rng = np.random.default_rng(77)
     n, m, k = 300, 200, 9
     A = rng.random((n, m))
@@ -395,7 +393,7 @@ def test_sharded_path_with_a_real_one_rank_rccl_communicator(monkeypatch, pname,
     for sharded in (False, True):
         with nnlm_amd.Handle(0, prec) as h:
             if sharded:
-                h.comm_init(_lib.comm_unique_id(), 0, 1)
+                h.comm_init(_lib.comm_unique_id(), 0, 1, form=form)
             h.set_matrix(A)
             h.set_factors(k, W0, H0, None, Hm)
             h.iterate(2, reg, reg, 6, 1e-9, 1)
@@ -441,7 +439,6 @@ def test_virtual_ranks_run_whole_sharded_half_steps(monkeypatch, pname, prec, to
     (phase 1), the host stand-in for ncclAllReduce sums the [Gram | cross-product] buffers, every rank sweeps ITS columns
     (phase 2), the stand-in for ncclAllGather distributes the packed slabs, every rank unpacks (phase 3).  All ranks must
     end with identical factors, equal to the single-rank result up to the all-reduce's summation order."""
-    monkeypatch.setenv("NNLM_SHARD_DENSE", "reduce")
     rng = np.random.default_rng(world + method)
     n, m = 500, 333
     A = rng.random((n, m))
@@ -458,7 +455,7 @@ def test_virtual_ranks_run_whole_sharded_half_steps(monkeypatch, pname, prec, to
     hs = [nnlm_amd.Handle(0, prec) for _ in range(world)]
     try:
         for rk, h in enumerate(hs):
-            h.comm_init(None, rk, world)
+            h.comm_init(None, rk, world, form="reduce")
             h.set_matrix(A)
             h.set_factors(k, W0, H0, Wm, None)
         for _ in range(2):

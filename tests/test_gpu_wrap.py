@@ -1,7 +1,7 @@
 """The persistent ("wrap-around") form of the SCD sweep (k_sweep_q.h, sweep_scd_qw_kernel): between one and two wavefronts of 16
 columns per SIMD the launch gives every CU G = 5 .. 7 column groups, which its four wavefronts share by McNaughton's rule -- a group
 cut by a piece boundary is started by one wavefront and finished by another, its state handed over through LDS.  Same arithmetic per
-column as the plain form, so the results must be BIT-IDENTICAL to it: the device is made to look small (NNLM_DEBUG_CUS, read by
+column as the plain form, so the results must be BIT-IDENTICAL to it: the device is made to look small (nnlm_debug_set_cus, read by
 nnlm_create) so that a few hundred columns take the persistent form, and the same problem is run on the plain form for comparison;
 both are also held against the oracle.  The benchmark's W half-step (20000 columns on 256 CUs: G = 5) takes this form at full size
 (tests/test_gpu_fullsize.py)."""
@@ -22,11 +22,12 @@ pytestmark = pytest.mark.gpu
 
 def _run(monkeypatch, cus, prec, A, k, W0, H0, Wm, Hm, reg, inner, tol, iters):
     """(W, H, sweeps) after `iters` outer iterations; iters = 'W' / 'H': ONE half-step from the given factors."""
-    if cus:
-        monkeypatch.setenv("NNLM_DEBUG_CUS", str(cus))
-    else:
-        monkeypatch.delenv("NNLM_DEBUG_CUS", raising=False)
-    with nnlm_amd.Handle(0, prec) as h:
+    _lib.debug_set_cus(cus)  # (test hook of the C ABI: handles created from now on plan their launches for `cus` compute units)
+    try:
+        h = nnlm_amd.Handle(0, prec)
+    finally:
+        _lib.debug_set_cus(0)
+    with h:
         h.set_matrix(A)
         h.set_factors(k, W0, H0, Wm, Hm)
         if iters in ("W", "H"):
