@@ -559,6 +559,9 @@ __device__ static inline float kl_wave_total(float v)
 #ifndef KLT_PBD
 #define KLT_PBD 5 // pass B: row elements requested this many chunks ahead
 #endif
+#ifndef KLT_PIN
+#define KLT_PIN 0 // 1: keep every chunk's arithmetic between its own row request and the next one (see pass A)
+#endif
 #ifndef KLT_EXP
 #define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests, 4 no pass B, 8 no pass A
 #endif
@@ -751,6 +754,15 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                         }
                     }
                 }
+#if KLT_PIN
+                // (the last piece's run-time test splits the unrolled loop into basic blocks, and the optimizer then SINKS the arithmetic of
+                //  every chunk -- pure values, used only by the reduction -- into the last block: all row requests and LDS reads came out in
+                //  one burst ahead of the whole pass.  An opaque use of the sums keeps a chunk's instructions where they are written.)
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) asm volatile("" : "+v"(acc[c][v]));
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
