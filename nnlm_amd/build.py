@@ -24,6 +24,20 @@ def sources():
         os.path.join(HERE, "..", "include", "nnlm_mi355x.h")]
 
 
+def unit_deps(src):
+    """The unit's source and every header it includes (quoted includes, transitively)."""
+    import re
+    seen, todo = set(), [os.path.abspath(src)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), re.M):
+            todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    return seen
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
@@ -32,9 +46,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA C/D operands in VGPRs (gfx950 has a unified register file); the sweep kernel
     # reads and rewrites single accumulator entries between MFMAs and would otherwise shuttle whole tiles VGPR<->AGPR
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
-    procs = []
-    for src in units():  # every unit at once: a few processes, each minutes long
+    procs, fresh = [], []
+    for src in units():  # every stale unit at once: a few processes, each minutes long
         obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in unit_deps(src)):
+            fresh.append(obj)  # (the unit and its headers are older than its object)
+            continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -47,6 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     q.kill()
             raise subprocess.CalledProcessError(p.returncode, cmd)
         objs.append(obj)
+    objs += fresh
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(link), file=sys.stderr)

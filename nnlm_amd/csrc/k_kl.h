@@ -513,6 +513,14 @@ __global__ __launch_bounds__(256) void wh_store64_kernel(const double *__restric
 // SIMD measured in isolation (scripts/exp/valu_exp.hip), i.e. ~1.0 ms per half-step at config 3.
 // Arithmetic differences from kl_update_kernel: fp32 state and quotients as kl_fast_kernel; tmp = num / den through
 // v_rcp_f64 + one Newton step; the rel-change test 2|d|/(..) > tol without the division.
+#ifndef KLT_TIMING
+#define KLT_TIMING 0 // 1: wavefront 0 of every workgroup accumulates the cycles it spends in each part of a step (scripts/exp/klt_exp.hip)
+#endif
+#ifndef KLT_V
+#define KLT_V 7 // step-loop arrangement of kl_tile_kernel (bits; 0 = the arrangement of rounds 2-4): 1 Lee's reciprocal denominator between
+                // the first chunks of pass A, row sum read at the top of the step; 2 wave totals of all columns side by side; 4 pass B's
+                // first row elements requested in front of the scalar part
+#endif
 struct KlTileArgs {
     const float *Adata; // column c at Adata + c * lda, contraction index contiguous
     size_t lda;         // (= ldyf, a multiple of 4)
@@ -535,6 +543,9 @@ struct KlTileArgs {
     void *op;
     int op_mode, op_ld;
     unsigned long long *sweeps;
+#if KLT_TIMING
+    unsigned long long *tim = nullptr; // [blocks][8] cycle counts of wavefront 0 (experiments only)
+#endif
 };
 
 template <int CTRL, int RMASK> __device__ static inline float kl_dpp(float oldv, float v)
@@ -560,7 +571,7 @@ __device__ static inline float kl_wave_total(float v)
 #define KLT_PBD 5 // pass B: row elements requested this many chunks ahead
 #endif
 #ifndef KLT_PIN
-#define KLT_PIN 0 // 1: keep every chunk's arithmetic between its own row request and the next one (see pass A)
+#define KLT_PIN 1 // 1: keep every chunk's arithmetic between its own row request and the next one (see pass A)
 #endif
 #ifndef KLT_EXP
 #define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests, 4 no pass B, 8 no pass A
@@ -577,9 +588,9 @@ __device__ static inline float kl_wave_total(float v)
 // dynamic LDS of kl_tile_kernel: two row buffers, coordinates and row sums of the C columns, reduction scratch
 // (a staged row is a whole number of 64 x 16-byte wavefront pieces: which pieces exist is then wave-uniform)
 __host__ __device__ static inline int kl_tile_p4(int p) { return ((p + 3) / 4 + 63) / 64 * 64; }
-__host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0, int nbuf = 2)
+__host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0, int nbuf = 2, int nw = 8)
 {
-    return nbuf * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * 8 * 4 + (size_t)C * mw_masked * 8;
+    return nbuf * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * (nw > 8 ? nw : 8) * 4 + (size_t)C * mw_masked * 8;
 }
 // s_waitcnt vmcnt(n), n wave-uniform at run time (0 .. 19: the pieces of a row a wavefront may have in flight)
 __device__ static inline void klt_wait_vm(int n)
@@ -596,11 +607,18 @@ __device__ static inline void klt_wait_vm(int n)
 // ONEBUF (contractions of 20481 .. ~40400: a row is up to 158 KB, one buffer is all the LDS holds): piece e of the NEXT row is
 // requested into its slot right after pass B has read piece e of this row back, and pass A waits for piece e with a counted
 // s_waitcnt -- the scheme of kl_reg64_kernel.  (Two buffers otherwise: the next row is requested during pass A.)
-template <int EPT4, int C, int METHOD, bool ONEBUF = false>
-__global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a)
+// NT = threads of the workgroup: 512 (one workgroup per CU, two of its wavefronts per SIMD) or 256 (TWO independent workgroups per CU, one
+// wavefront of each per SIMD: while one workgroup reduces, waits at its barrier, runs its scalar part or loads its next columns, the other
+// one's vector passes have the SIMDs -- what the lock step of a single workgroup's eight wavefronts cannot give; its LDS request must
+// stay at or below 80 KB, i.e. one row buffer for contractions beyond ~5000).
+template <int EPT4, int C, int METHOD, bool ONEBUF = false, int NT = KLT_THREADS>
+__global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl_tile_kernel(const KlTileArgs a)
 {
     constexpr int NV = (METHOD == 4) ? 1 : 2; // sums per column and step: {num} or {a, b}
     constexpr int NROWBUF = ONEBUF ? 1 : 2;
+    constexpr int NW = NT / 64;               // wavefronts of the workgroup
+    constexpr int KV = (ONEBUF && EPT4 >= 19) ? (KLT_V & 2) : KLT_V; // (160 state registers at 20 pieces: nothing more may stay live across a pass)
+    constexpr int RS = NW > 8 ? NW : 8;       // wave totals per sum in the reduction scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char kl_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: scalar branches)
     const int k = a.k, P4 = kl_tile_p4(a.p); // float4 slots per row, padded to whole wavefront pieces (the arrays are padded further)
@@ -608,19 +626,19 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     double *xs = (double *)(kl_smem + NROWBUF * (size_t)rowb); // [C][k]
     double *sws = xs + C * k;                            // [C][k]
     float *red = (float *)(sws + C * k);                 // [2][NV * C][8]
-    unsigned long long *mks = (unsigned long long *)(red + 2 * 2 * C * 8); // [C][mw] mask words of the block's columns (a.mask only)
+    unsigned long long *mks = (unsigned long long *)(red + 2 * 2 * C * RS); // [C][mw] mask words of the block's columns (a.mask only)
     const int col0 = a.colbase + blockIdx.x * C;
     const float tiny = (float)NNLM_TINY;
 
     // Pieces e = 0 .. EPT4-1 of a row (float4 slots e * 512 + 64 * wave + lane) belong to this wavefront: it loads them, reads
     // them back and owns the matching chunks of the state.  EPT4 = ceil(P4 / 512) exactly (the host picks the instantiation), so
     // every piece but the last exists for every wavefront and only `last` is a run-time (wave-uniform) condition.
-    const bool last = (EPT4 - 1) * KLT_THREADS + wave * 64 < P4;
+    const bool last = (EPT4 - 1) * NT + wave * 64 < P4;
 #define KLT_HAS(e_) ((e_) + 1 < EPT4 || last)
     // Slots at or beyond L4 = ld / 4 (only in a row's last piece; the arrays end there) are never loaded: they are zeroed here
     // once in both buffers, their state entries are b = 0, y = 1, so they add nothing and never change.
     const int voff = lane * 16, L4 = (int)(a.lda >> 2);
-    for (int i = L4 + tid; i < P4; i += KLT_THREADS) {
+    for (int i = L4 + tid; i < P4; i += NT) {
         *(f32x4 *)(kl_smem + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!ONEBUF) *(f32x4 *)(kl_smem + (size_t)rowb + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -631,15 +649,15 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     //  the builtin form spent ~10 scalar and vector instructions per piece on 64-bit per-lane addresses)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)kl_smem + (unsigned)wave * 1024u;
     auto issue_piece = [&](int q, int bufsel, int e) {
-        const unsigned char *src = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024 + (size_t)e * (KLT_THREADS * 16); // wave-uniform
-        const unsigned dst = lds0 + (unsigned)bufsel * (unsigned)rowb + (unsigned)e * (KLT_THREADS * 16);
+        const unsigned char *src = (const unsigned char *)(a.Yf + (size_t)q * a.ldyf) + (size_t)wave * 1024 + (size_t)e * (NT * 16); // wave-uniform
+        const unsigned dst = lds0 + (unsigned)bufsel * (unsigned)rowb + (unsigned)e * (NT * 16);
         const unsigned long long sp = (unsigned long long)src;
         const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)sp);
         const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
         // (only slots of the LAST piece can lie beyond the end of the arrays: L4 >= 512 (EPT4 - 1) + 64 wave whenever that piece exists)
         if ((KLT_EXP & 2) && q > 1) return;
-        if (e + 1 < EPT4 || e * KLT_THREADS + wave * 64 + lane < L4)
+        if (e + 1 < EPT4 || e * NT + wave * 64 + lane < L4)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(su), "s"(du) : "memory");
     };
     auto issue = [&](int q, int bufsel) {
@@ -663,8 +681,8 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         live_l = !all;
     }
     if (a.mask)
-        for (int e = tid; e < C * a.mw; e += KLT_THREADS) mks[e] = (col0 + e / a.mw < a.ncols) ? a.mask[(size_t)col0 * a.mw + e] : ~0ull;
-    for (int e = tid; e < C * k; e += KLT_THREADS) {
+        for (int e = tid; e < C * a.mw; e += NT) mks[e] = (col0 + e / a.mw < a.ncols) ? a.mask[(size_t)col0 * a.mw + e] : ~0ull;
+    for (int e = tid; e < C * k; e += NT) {
         const int c = e / k, q = e - c * k, col = col0 + c;
         xs[e] = (col < a.ncols) ? a.X[(size_t)q * a.ldx + col] : 0.0;
         sws[e] = (col < a.ncols) ? (a.sumw_cols ? a.sumw_cols[(size_t)col * a.ldsw + q] : a.sumw[q]) : 1.0;
@@ -677,7 +695,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         const f32x4 *Ac = (const f32x4 *)(a.Adata + (size_t)col * a.lda), *Yc = (const f32x4 *)(a.Yinit + (size_t)col * a.lda);
 #pragma unroll
         for (int e = 0; e < EPT4; e++) {
-            const int idx4 = e * KLT_THREADS + tid;
+            const int idx4 = e * NT + tid;
             const bool valid = KLT_HAS(e) && idx4 < L4 && col0 + c < a.ncols;
             b[c][e] = valid ? Ac[idx4] : f32x4{0.f, 0.f, 0.f, 0.f};
             y[c][e] = valid ? Yc[idx4] : f32x4{1.f, 1.f, 1.f, 1.f};
@@ -693,6 +711,21 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             y[c][e] = y[c][e] + tiny;
         }
     __syncthreads();
+#if KLT_TIMING
+    // T[i] += cycles since the previous mark: 0 prologue / loop overhead, 1 top of the step (row wait, LDS reads of the coordinate), 2 pass A,
+    // 3 wave totals, 4 barrier, 5 scalar part, 6 pass B, 7 epilogue
+    unsigned long long tT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#define KLT_T(i_)                                                                             \
+    do {                                                                                      \
+        unsigned long long tn_;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory");          \
+        tT[i_] += tn_ - tprev;                                                                \
+        tprev = tn_;                                                                          \
+    } while (0)
+#else
+#define KLT_T(i_) do { } while (0)
+#endif
     const unsigned long long cmask = (C >= 64) ? ~0ull : ((1ull << C) - 1ull); // lanes that own a column
     double S_l = 0.0;
     for (int q = 0; q < k; q++) S_l += xs[lc * k + q];
@@ -704,6 +737,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     while (any) { // block-uniform: every wavefront holds the same per-lane column state
         flag_l = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {
+            KLT_T(0);
             const int qn = (q + 1 < k) ? q + 1 : 0; // next row (row 0 again for a sweep that may follow)
             if (!ONEBUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's pieces of row q (requested during step q - 1) have landed
             const unsigned char *rowp = kl_smem + (ONEBUF ? 0 : (size_t)bufsel * rowb);
@@ -717,6 +751,19 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
             //  is a second path into the loop latch, and the compiler then writes every updated state chunk to a NEW register and
             //  copies 80 registers back per step)
             const double xq_l = xs[lc * k + q]; // read BEFORE the barrier: wavefront 0 rewrites it after
+            const double sw_l = sws[lc * k + q];
+            // Lee: the denominator (src/base_algorithms.cpp:142) does not depend on this step's sums: den, its reciprocal and the Newton step
+            // are three short dependent fp64 chains, issued one each behind the first chunks of pass A (where both wavefronts of a SIMD have
+            // vector work to cover them) instead of between the pass and the barrier (where every wavefront of the block waited on them)
+            double den4 = 1.0, rd4 = 0.0;
+            auto rd_stage = [&](int st) {
+                if (METHOD != 4) return;
+                if (st == 0) den4 = sw_l + a.r0 * xq_l + a.r1 * (S_l - xq_l) + a.r2; // :142
+                else if (st == 1) rd4 = __builtin_amdgcn_rcp(den4);
+                else rd4 = __builtin_fma(__builtin_fma(-den4, rd4, 1.0), rd4, rd4);
+                asm volatile("" : "+v"(den4), "+v"(rd4)); // (stays where it is written)
+            };
+            KLT_T(1);
             f32x4 acc[C][NV];
 #pragma unroll
             for (int c = 0; c < C; c++)
@@ -724,7 +771,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                 for (int v = 0; v < NV; v++) acc[c][v] = f32x4{0.f, 0.f, 0.f, 0.f};
             // the row element of chunk e + 1 is fetched from LDS while chunk e is processed; the scheduling barrier keeps the
             // compiler from hoisting all EPT4 fetches (and their registers) to the top of the unrolled loop
-            auto wload = [&](int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * KLT_THREADS + tid) * 16); };
+            auto wload = [&](int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * NT + tid) * 16); };
             f32x4 wq[2]; // (two named registers by the parity of e: no copy per chunk)
             if (ONEBUF) klt_wait_vm(npm1); // piece 0 has landed once at most the npm1 younger ones are outstanding
             wq[0] = wload(0);
@@ -754,6 +801,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                         }
                     }
                 }
+                if ((KV & 1) && e < 3) rd_stage(e);
 #if KLT_PIN
                 // (the last piece's run-time test splits the unrolled loop into basic blocks, and the optimizer then SINKS the arithmetic of
                 //  every chunk -- pure values, used only by the reduction -- into the last block: all row requests and LDS reads came out in
@@ -765,32 +813,71 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+            for (int st = ((KV & 1) ? (EPT4 < 3 ? EPT4 : 3) : 0); st < 3; st++) rd_stage(st); // (what found no chunk to ride on)
+            KLT_T(2);
+            if (KV & 2) { // the C * NV wave totals side by side: six dependent DPP steps for all of them, not six per sum one after the other
+                float t[C][NV];
 #pragma unroll
-            for (int c = 0; c < C; c++)
+                for (int c = 0; c < C; c++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    const float t = kl_wave_total((acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]));
-                    if (lane == 63) red[((par * C + c) * NV + v) * 8 + wave] = t;
+                    for (int v = 0; v < NV; v++) t[c][v] = (acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]);
+#define KLT_RSTEP(CTRL, RM)                                    \
+    _Pragma("unroll") for (int c = 0; c < C; c++)              \
+        _Pragma("unroll") for (int v = 0; v < NV; v++) t[c][v] += kl_dpp<CTRL, RM>(0.f, t[c][v]);
+                KLT_RSTEP(0xB1, 0xF)
+                KLT_RSTEP(0x4E, 0xF)
+                KLT_RSTEP(0x141, 0xF)
+                KLT_RSTEP(0x140, 0xF)
+                KLT_RSTEP(0x142, 0xA)
+                KLT_RSTEP(0x143, 0xC)
+#undef KLT_RSTEP
+                if (lane == 63) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) red[((par * C + c) * NV + v) * RS + wave] = t[c][v];
                 }
-            // Lee: the denominator (src/base_algorithms.cpp:142) does not depend on this step's sums -- its reciprocal is formed in
-            // front of the barrier, and only  sum * rd, (tmp - 1) x  remain between the barrier and pass B
-            double rd4 = 0.0;
-            if (METHOD == 4) {
-                const double den = sws[lc * k + q] + a.r0 * xq_l + a.r1 * (S_l - xq_l) + a.r2; // :142
-                rd4 = __builtin_amdgcn_rcp(den);
-                rd4 = __builtin_fma(__builtin_fma(-den, rd4, 1.0), rd4, rd4);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        const float t = kl_wave_total((acc[c][v][0] + acc[c][v][1]) + (acc[c][v][2] + acc[c][v][3]));
+                        if (lane == 63) red[((par * C + c) * NV + v) * RS + wave] = t;
+                    }
             }
+            KLT_T(3);
             if (!(KLT_EXP & 1)) KLT_BARRIER();
+            KLT_T(4);
+            // pass B's first row elements are requested here, behind the reads of the wave totals and in front of the scalar part: they
+            // arrive while it runs (KV & 4; otherwise in front of the pass itself)
+            constexpr int PDW = (NT == 1024) ? 2 : KLT_PBD; // (four wavefronts per SIMD cover an LDS round trip with less of it in flight, and have half the registers)
+            constexpr int PD = ONEBUF ? KLT_PBD1 : ((EPT4 < PDW) ? EPT4 : PDW);
+            f32x4 wb[PD + 1];
             float coef_l = 0.f;
             if (KLT_EXP & 1) coef_l = 1e-12f * (acc[0][0][0] + acc[C - 1][NV - 1][3]);
             else {
+                f32x4 rrv[NV][NW / 4]; // the wave totals of the lane's column (fp32, like the totals themselves)
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int u = 0; u < NW / 4; u++) rrv[v][u] = *(const f32x4 *)(red + ((par * C + lc) * NV + v) * RS + 4 * u);
+                if (KV & 4) {
+#pragma unroll
+                    for (int e = 0; e < PD; e++)
+                        if (KLT_HAS(e)) wb[e] = wload(e);
+                }
                 double sv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float *rr = red + ((par * C + lc) * NV + v) * 8; // eight wave totals (fp32, like the totals themselves)
-                    sv[v] = (double)(((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7])));
+                    float t4 = (rrv[v][0][0] + rrv[v][0][1]) + (rrv[v][0][2] + rrv[v][0][3]);
+                    if (NW >= 8) t4 = t4 + ((rrv[v][1][0] + rrv[v][1][1]) + (rrv[v][1][2] + rrv[v][1][3]));
+                    if (NW == 16)
+                        t4 = t4 + (((rrv[v][NW / 4 - 2][0] + rrv[v][NW / 4 - 2][1]) + (rrv[v][NW / 4 - 2][2] + rrv[v][NW / 4 - 2][3])) +
+                                   ((rrv[v][NW / 4 - 1][0] + rrv[v][NW / 4 - 1][1]) + (rrv[v][NW / 4 - 1][2] + rrv[v][NW / 4 - 1][3])));
+                    sv[v] = (double)t4;
                 }
-                const double sw = sws[lc * k + q];
+                const double sw = sw_l;
                 if (METHOD == 4) {
                     const double tmp = sv[0] * rd4;
                     const double d = (tmp - 1) * xq_l; // :143
@@ -821,15 +908,16 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
 #pragma unroll
             for (int c = 0; c < C; c++) coef[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef_l), c));
             par ^= 1;
+            KLT_T(5);
             { // pass B: y += coef * w for every column of the block, unconditionally (coef = 0 leaves a state as it is: a branch around
               // the pass makes the compiler copy all state registers where the two paths meet)
                 // (two fused multiply-adds per chunk and column do not cover an LDS round trip: with the row element one chunk ahead, as
                 //  in pass A, the pass waited ~100 cycles per chunk -- 0.8-1.0 of a half-step's 2.3 ms at config 3; KLT_PBD chunks ahead)
-                constexpr int PD = ONEBUF ? KLT_PBD1 : ((EPT4 < KLT_PBD) ? EPT4 : KLT_PBD);
-                f32x4 wb[PD + 1];
+                if (!(KV & 4) || (KLT_EXP & 1)) {
 #pragma unroll
-                for (int e = 0; e < PD; e++)
-                    if (KLT_HAS(e)) wb[e] = wload(e);
+                    for (int e = 0; e < PD; e++)
+                        if (KLT_HAS(e)) wb[e] = wload(e);
+                }
 #pragma unroll
                 for (int e = 0; e < ((KLT_EXP & 4) ? 0 : EPT4); e++) {
                     if (KLT_HAS(e)) { // wave-uniform
@@ -845,6 +933,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            KLT_T(6);
         }
         KLT_BARRIER(); // xs[] written by thread 0 during this sweep is read by everyone in the next
         if (run_l) {
@@ -855,7 +944,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the row requested for a sweep that did not follow
     __syncthreads();
-    for (int e = tid; e < C * k; e += KLT_THREADS) {
+    for (int e = tid; e < C * k; e += NT) {
         const int c = e / k, q = e - c * k, col = col0 + c;
         if (col < a.ncols) {
             const double xv = xs[e];
@@ -867,6 +956,12 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile_kernel(const KlTileArgs a
         const long long tot = wave_sum_ll((lane < C) ? (long long)tdone_l : 0ll);
         if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
     }
+#if KLT_TIMING
+    KLT_T(7);
+    if (a.tim && tid == 0)
+        for (int i = 0; i < 8; i++) a.tim[(size_t)blockIdx.x * 8 + i] = tT[i];
+#endif
+#undef KLT_T
 #undef KLT_HAS
 }
 

@@ -138,15 +138,17 @@ constexpr SqSched sq_sched(int NL)
     return s;
 }
 
-// What every sweep workgroup leaves behind from its final x image xl[COLS][KP + 2] (columns col_base .. col_base + COLS - 1): the
-// factor outputs, max|x| and the Gram partial sums of its columns (slab `slab_idx`) for the next half-step.
-template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(const SweepArgs &a, const double *xl, int col_base, int slab_idx)
+// What every sweep workgroup leaves behind from its final x image xl[columns][KP + 2] (columns col_base .. col_base + columns - 1): the
+// factor outputs, max|x| and the Gram partial sums of its columns (slab `slab_idx`) for the next half-step.  COLS > 0: that many
+// columns, known at compile time (plain form: 64); COLS = 0: `ncl` of them (persistent form: 16 G, a multiple of 16).
+template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(const SweepArgs &a, const double *xl, int ncl, int col_base, int slab_idx)
 {
     constexpr int KP = 16 * NT, XS = KP + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
+    const int ncols_wg = COLS ? COLS : ncl;
     float xmax = 0.0f;
-    for (int e = tid; e < COLS * KP; e += SWEEPQ_THREADS) {
-        const int q = e / COLS, c = e % COLS, ecol = col_base + c;
+    for (int e = tid; e < ncols_wg * KP; e += SWEEPQ_THREADS) {
+        const int q = e / ncols_wg, c = e % ncols_wg, ecol = col_base + c;
         if (q < k && ecol < a.ncols) {
             const double xv = xl[c * XS + q];
             xmax = fmaxf(xmax, fabsf((float)xv));
@@ -174,8 +176,8 @@ template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(cons
             for (int tb = ta; tb < NT; tb++) {
                 if ((tix++ & 3) != wave) continue;
                 f64x4 g = f64x4{0, 0, 0, 0};
-#pragma unroll
-                for (int s4 = 0; s4 < COLS / 4; s4++) {
+#pragma unroll(COLS ? COLS / 4 : 1)
+                for (int s4 = 0; s4 < ncols_wg / 4; s4++) {
                     const double *xr = xl + (4 * s4 + lg) * XS + l15;
                     g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
                 }
@@ -184,6 +186,85 @@ template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(cons
             }
     }
 }
+
+// ---- one block of the sweep: the step both kernel forms take (sweepq16_body, sweep_scd_qw_kernel) -----------------------------------
+// Expands to a generic lambda (block B, rel-change tests on / off) inside a scope that holds: As[2][2 NP] (operand sets by block
+// parity), acc[NB], x[NB], d_pend, Lc, rinvc, gdc, flag, tol, tolh, tolhe, fetch(), the template parameters NB, NP, STRICT -- and, with
+// SWEEPQ_DEBUG, the harness's dump hook.  The step is four stages  [v_max]  pre  [dependent MFMA]  post : three chain passes and the
+// urgent product.  `pre` / `post` are lazy products of the PREVIOUS block's deltas (independent of the chain): they fill the issue slots
+// the dependent instructions would otherwise wait through.  The v_max is inline asm, which the compiler's hazard recogniser does not
+// look into, so the wait states are provided here: a VALU result needs 2 wait states before a DGEMM reads it (one 4-pass MFMA in
+// between = 4), a 4x4x4 DGEMM result 6 before a VALU reads it (two MFMAs = 8); where a block count leaves a slot without lazy products,
+// s_nop stands in.  (Found the hard way: without them v_max reads the accumulator's OLD value -- every x doubled per sweep.)  The
+// scheduling barriers pin the order.
+#define SQ_IC(v) std::integral_constant<int, (v)> {}
+#define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if constexpr (STRICT) {                                                                                             \
+        const double q0 = (val_in) * rinvc; /* mu / G[q][q], correctly rounded: reciprocal + one Markstein correction */ \
+        const double qq = __builtin_fma(__builtin_fma(-q0, gdc, (val_in)), rinvc, q0);                                  \
+        tmpx = __builtin_fmax(xb - qq, 0.0); /* src/base_algorithms.cpp:23-24 */                                         \
+        c = tmpx - xb;                                                                                                  \
+    } else                                                                                                              \
+        c = sq_delta(xb, val_in);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
+    lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    dep_expr;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
+    sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef SWEEPQ_ABL_NOFETCH /* (harness ablation: timing without the operand fetches) */
+#define SQ_FETCH_AC()
+#else
+#define SQ_FETCH_AC() fetch(bc, Ac) /* (the previous step's lazy products were the last readers of this set) */
+#endif
+#define SWEEPQ_STEP_LAMBDA(DBG_HOOK)                                                                                                   \
+    [&](auto bc, auto tc) {                                                                                                            \
+        constexpr int B = decltype(bc)::value, BN = (B + 1) % NB;                                                                      \
+        constexpr bool TEST = decltype(tc)::value;                                                                                     \
+        constexpr SqSched S = sq_sched(NB - 1);                                                                                        \
+        double(&Ap)[2 * NP] = As[(B + 1) & 1]; /* operands of the previous block (lazy products) */                                     \
+        double(&Ac)[2 * NP] = As[B & 1];       /* operands of this block: fetched now, first used by the urgent product */              \
+        const double m0 = acc[B], xb = x[B];                                                                                           \
+        auto lazies = [&](auto fromc, auto toc) { /* lazy products number from .. to - 1, the next block's accumulator first */         \
+            sq_for<decltype(fromc)::value, decltype(toc)::value>([&](auto oc) {                                                        \
+                constexpr int T = (B + 1 + decltype(oc)::value) % NB;                                                                  \
+                acc[T] = sq_mfma(Ap[T], d_pend, acc[T]);                                                                               \
+            });                                                                                                                        \
+        };                                                                                                                             \
+        double c, m, tmpx = 0.0;                                                                                                       \
+        SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))                                                                                        \
+        SQ_FETCH_AC();                                                                                                                 \
+        SQ_STAGE(1, m, m = sq_mfma(Lc, c, m0))                                                                                         \
+        SQ_STAGE(2, m, m = sq_mfma(Lc, c, m0))                                                                                         \
+        /* the fourth stage's dependent product is the urgent one: the next block's gradient (its lazy product came first above) */    \
+        SQ_STAGE(3, m, acc[BN] = sq_mfma(Ac[BN], c, acc[BN]))                                                                          \
+        const double d = c;                                                                                                            \
+        /* rel-change test (src/base_algorithms.cpp:29-32): fp32-operand mode division-free, 2|d| > tol (x + d + x + eps); strict mode \
+           the rounded quotient's decision (rel_change_exceeds, common.h: the division only where the two sides agree to ~2 ulp) */    \
+        if (TEST) {                                                                                                                    \
+            if constexpr (STRICT) flag |= rel_change_exceeds(2.0 * fabs(d), tmpx + xb + NNLM_TINY, tol); /* (d = 0 when tmp == Hj(k): the reference's `continue`) */ \
+            else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);                                              \
+        }                                                                                                                              \
+        x[B] = STRICT ? tmpx : xb + d; /* (strict: Hj(k) = tmp itself, src/base_algorithms.cpp:33) */                                   \
+        DBG_HOOK                                                                                                                       \
+        d_pend = d;                                                                                                                    \
+        Lc = Ac[NB];                                                                                                                   \
+        if constexpr (STRICT) rinvc = Ac[NB + 1], gdc = Ac[NB + 2];                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    }
+#ifdef SWEEPQ_DEBUG
+#define SQ_DBG_DUMP                                                                                                                    \
+    if (a.op_mode == 99 && t == 0 && blockIdx.x == 0 && wave == 0) {                                                                   \
+        double *dbg = (double *)a.op + 1024 + B * 6 * 64;                                                                              \
+        dbg[lane] = xb, dbg[64 + lane] = m0, dbg[128 + lane] = m, dbg[192 + lane] = d, dbg[256 + lane] = x[B], dbg[320 + lane] = d_pend; \
+    }
+#else
+#define SQ_DBG_DUMP
+#endif
 
 // LDS of one 16-column-per-wavefront workgroup: the x image and the operand image
 __host__ __device__ static inline size_t sweepq_lds_bytes(int KP, int NB, bool strict) { return ((size_t)SWEEPQ_COLS * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB) * 8; }
@@ -292,75 +373,8 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
     double rinvc = STRICT ? As[1][NB + 1] : 0.0, gdc = STRICT ? As[1][NB + 2] : 0.0; // strict: 1 / G[q][q] and G[q][q] of the current block's coordinates
     sq_nop<8>(); // (the initial gradients come out of MFMAs; the first v_max below is inline asm)
 
-    // One block.  The step is four stages  [v_max]  pre  [dependent MFMA]  post : three chain passes and the urgent product.
-    // `pre` / `post` are lazy products of the PREVIOUS block's deltas (independent of the chain): they fill the issue slots the
-    // dependent instructions would otherwise wait through.  The v_max is inline asm, which the compiler's hazard recogniser
-    // does not look into, so the wait states are provided here: a VALU result needs 2 wait states before a DGEMM reads it
-    // (one 4-pass MFMA in between = 4), a 4x4x4 DGEMM result 6 before a VALU reads it (two MFMAs = 8); where a block count
-    // leaves a slot without lazy products, s_nop stands in.  (Found the hard way: without them v_max reads the accumulator's
-    // OLD value -- every x doubled per sweep.)  The scheduling barriers pin the order.
-    auto step = [&](auto bc, auto tc) {
-        constexpr int B = decltype(bc)::value, BN = (B + 1) % NB;
-        constexpr bool TEST = decltype(tc)::value;
-        constexpr SqSched S = sq_sched(NB - 1);
-        double(&Ap)[2 * NP] = As[(B + 1) & 1]; // operands of the previous block (lazy products)
-        double(&Ac)[2 * NP] = As[B & 1];       // operands of this block: fetched now, first used by the urgent product
-        const double m0 = acc[B], xb = x[B];
-        auto lazies = [&](auto fromc, auto toc) { // lazy products number from .. to - 1, the next block's accumulator first
-            sq_for<decltype(fromc)::value, decltype(toc)::value>([&](auto oc) {
-                constexpr int T = (B + 1 + decltype(oc)::value) % NB;
-                acc[T] = sq_mfma(Ap[T], d_pend, acc[T]);
-            });
-        };
-#define SQ_IC(v) std::integral_constant<int, (v)> {}
-#define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    if constexpr (STRICT) {                                                                                             \
-        const double q0 = (val_in) * rinvc; /* mu / G[q][q], correctly rounded: reciprocal + one Markstein correction */ \
-        const double qq = __builtin_fma(__builtin_fma(-q0, gdc, (val_in)), rinvc, q0);                                  \
-        tmpx = __builtin_fmax(xb - qq, 0.0); /* src/base_algorithms.cpp:23-24 */                                         \
-        c = tmpx - xb;                                                                                                  \
-    } else                                                                                                              \
-        c = sq_delta(xb, val_in);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
-    lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    dep_expr;                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
-    sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
-    __builtin_amdgcn_sched_barrier(0);
-        double c, m, tmpx = 0.0;
-        SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))
-#ifndef SWEEPQ_ABL_NOFETCH // (harness ablation: timing without the operand fetches)
-        fetch(bc, Ac); // (the previous step's lazy products were the last readers of this set)
-#endif
-        SQ_STAGE(1, m, m = sq_mfma(Lc, c, m0))
-        SQ_STAGE(2, m, m = sq_mfma(Lc, c, m0))
-        // the fourth stage's dependent product is the urgent one: the next block's gradient (its lazy product came first above)
-        SQ_STAGE(3, m, acc[BN] = sq_mfma(Ac[BN], c, acc[BN]))
-#undef SQ_STAGE
-#undef SQ_IC
-        const double d = c;
-        // rel-change test (src/base_algorithms.cpp:29-32): fp32-operand mode division-free, 2|d| > tol (x + d + x + eps); strict mode the
-        // rounded quotient's decision (rel_change_exceeds, common.h: the division only where the two sides agree to ~2 ulp)
-        if (TEST) {
-            if constexpr (STRICT) flag |= rel_change_exceeds(2.0 * fabs(d), tmpx + xb + NNLM_TINY, tol); // (d = 0 when tmp == Hj(k): the reference's `continue`)
-            else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
-        }
-        x[B] = STRICT ? tmpx : xb + d; // (strict: Hj(k) = tmp itself, src/base_algorithms.cpp:33)
-#ifdef SWEEPQ_DEBUG
-        if (a.op_mode == 99 && t == 0 && blockIdx.x == 0 && wave == 0) {
-            double *dbg = (double *)a.op + 1024 + B * 6 * 64;
-            dbg[lane] = xb, dbg[64 + lane] = m0, dbg[128 + lane] = m, dbg[192 + lane] = d, dbg[256 + lane] = x[B], dbg[320 + lane] = d_pend;
-        }
-#endif
-        d_pend = d;
-        Lc = Ac[NB];
-        if constexpr (STRICT) rinvc = Ac[NB + 1], gdc = Ac[NB + 2];
-        __builtin_amdgcn_sched_barrier(0);
-    };
+    // One block: SWEEPQ_STEP_LAMBDA (above), shared with the persistent form
+    auto step = SWEEPQ_STEP_LAMBDA(SQ_DBG_DUMP);
     // some live column of the wavefront has no coordinate yet that moved by more than rel_tol
     auto tests_needed = [&]() -> bool {
         const unsigned long long bal = __ballot(flag);
@@ -395,7 +409,7 @@ __device__ __forceinline__ void sweepq16_body(const SweepArgs &a, const double *
     if (act) write_col();
     __syncthreads(); // x image final
 
-    sweepq_epilogue<NT, SWEEPQ_COLS>(a, xl, col_base, (int)blockIdx.x);
+    sweepq_epilogue<NT, SWEEPQ_COLS>(a, xl, SWEEPQ_COLS, col_base, (int)blockIdx.x);
     {
         const long long tot = wave_sum_ll((ri == 0) ? (long long)t_lane : 0ll);
         if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
@@ -425,54 +439,11 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, ((HAS_MASK && (NB >= 15 || (STRICT 
 // request so that two cannot share one), 256 threads, one wavefront per SIMD at any time: G = 5 at the benchmark's W half-step, T = 63
 // sweeps instead of 100.  Same arithmetic, same order of operations per column as the plain form: results are bit-identical.
 // =====================================================================================================================================
-#define SWEEPQ_WRAP_MAXG 7
+#define SWEEPQ_WRAP_MAXG 10 // (x image of 16 G columns + operand image + three hand-over slots: 154 KB at k = 64 in the strict mode)
 __host__ __device__ static inline size_t sweepqw_slot_doubles(int NB) { return (size_t)(2 * NB + 1) * 64 + 64; } // per lane: x, gradients, owed deltas; (act, sweeps) as ints
 __host__ __device__ static inline size_t sweepqw_lds_bytes(int KP, int NB, bool strict, int G)
 {
     return ((size_t)16 * G * (KP + 2) + (size_t)NB * sweepq_np(NB, strict) * 32 + 4 * NB + 3 * sweepqw_slot_doubles(NB)) * 8 + 64;
-}
-
-// sweepq_epilogue for a run-time number of columns (a multiple of 16)
-template <int NT> __device__ __forceinline__ void sweepqw_epilogue(const SweepArgs &a, const double *xl, int ncl, int col_base, int slab_idx)
-{
-    constexpr int KP = 16 * NT, XS = KP + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
-    float xmax = 0.0f;
-    for (int e = tid; e < ncl * KP; e += SWEEPQ_THREADS) {
-        const int q = e / ncl, c = e % ncl, ecol = col_base + c;
-        if (q < k && ecol < a.ncols) {
-            const double xv = xl[c * XS + q];
-            xmax = fmaxf(xmax, fabsf((float)xv));
-            a.Xout[(size_t)q * a.ldo + (ecol - a.ocol0)] = xv;
-            if (a.op_mode == 1) {
-                if (a.op_f64) ((double *)a.op)[(size_t)q * a.op_ld + ecol] = xv;
-                else ((float *)a.op)[(size_t)q * a.op_ld + ecol] = (float)xv;
-            }
-        }
-    }
-    if (a.maxbits) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
-        if (lane == 0 && xmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(xmax));
-    }
-    if (a.gram_slabs) {
-        const int l15 = lane & 15, lg = lane >> 4;
-        double *slab = a.gram_slabs + (size_t)slab_idx * KP * KP;
-        int tix = 0;
-#pragma unroll
-        for (int ta = 0; ta < NT; ta++)
-#pragma unroll
-            for (int tb = ta; tb < NT; tb++) {
-                if ((tix++ & 3) != wave) continue;
-                f64x4 g = f64x4{0, 0, 0, 0};
-                for (int s4 = 0; s4 < ncl / 4; s4++) {
-                    const double *xr = xl + (4 * s4 + lg) * XS + l15;
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[16 * ta], xr[16 * tb], g, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) slab[(16 * ta + lg + 4 * r) * KP + 16 * tb + l15] = g[r];
-            }
-    }
 }
 
 template <int NT, int NB, bool HAS_MASK, bool STRICT>
@@ -598,58 +569,8 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 1) void sweep_scd_qw_kernel(const S
     const double tol = a.rel_tol, tolh = 0.5 * tol, tolhe = 0.5 * tol * NNLM_TINY;
     bool flag = false;
     double Lc = 0.0, rinvc = 0.0, gdc = 0.0;
-    // One block -- identical to the step of the plain form (sweepq16_body: stages, hazards and scheduling barriers explained there)
-    auto step = [&](auto bc, auto tc) {
-        constexpr int B = decltype(bc)::value, BN = (B + 1) % NB;
-        constexpr bool TEST = decltype(tc)::value;
-        constexpr SqSched S = sq_sched(NB - 1);
-        double(&Ap)[2 * NP] = As[(B + 1) & 1];
-        double(&Ac)[2 * NP] = As[B & 1];
-        const double m0 = acc[B], xb = x[B];
-        auto lazies = [&](auto fromc, auto toc) {
-            sq_for<decltype(fromc)::value, decltype(toc)::value>([&](auto oc) {
-                constexpr int T = (B + 1 + decltype(oc)::value) % NB;
-                acc[T] = sq_mfma(Ap[T], d_pend, acc[T]);
-            });
-        };
-#define SQ_IC(v) std::integral_constant<int, (v)> {}
-#define SQ_STAGE(s_, val_in, dep_expr)                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    if constexpr (STRICT) {                                                                                             \
-        const double q0 = (val_in) * rinvc;                                                                             \
-        const double qq = __builtin_fma(__builtin_fma(-q0, gdc, (val_in)), rinvc, q0);                                  \
-        tmpx = __builtin_fmax(xb - qq, 0.0);                                                                            \
-        c = tmpx - xb;                                                                                                  \
-    } else                                                                                                              \
-        c = sq_delta(xb, val_in);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    sq_nop<(S.pre[s_] == 0 ? 2 : 0)>();                                                                                 \
-    lazies(SQ_IC(S.off[2 * (s_)]), SQ_IC(S.off[2 * (s_)] + S.pre[s_]));                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    dep_expr;                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    lazies(SQ_IC(S.off[2 * (s_) + 1]), SQ_IC(S.off[2 * (s_) + 1] + S.post[s_]));                                          \
-    sq_nop<(S.post[s_] == 0 ? 6 : (S.post[s_] == 1 ? 2 : 0))>();                                                        \
-    __builtin_amdgcn_sched_barrier(0);
-        double c, m, tmpx = 0.0;
-        SQ_STAGE(0, m0, m = sq_mfma(Lc, c, m0))
-        fetch(bc, Ac);
-        SQ_STAGE(1, m, m = sq_mfma(Lc, c, m0))
-        SQ_STAGE(2, m, m = sq_mfma(Lc, c, m0))
-        SQ_STAGE(3, m, acc[BN] = sq_mfma(Ac[BN], c, acc[BN]))
-#undef SQ_STAGE
-#undef SQ_IC
-        const double d = c;
-        if (TEST) {
-            if constexpr (STRICT) flag |= rel_change_exceeds(2.0 * fabs(d), tmpx + xb + NNLM_TINY, tol);
-            else flag |= fabs(d) > __builtin_fma(tolh, __builtin_fma(2.0, xb, d), tolhe);
-        }
-        x[B] = STRICT ? tmpx : xb + d;
-        d_pend = d;
-        Lc = Ac[NB];
-        if constexpr (STRICT) rinvc = Ac[NB + 1], gdc = Ac[NB + 2];
-        __builtin_amdgcn_sched_barrier(0);
-    };
+    // One block: the step of the plain form (SWEEPQ_STEP_LAMBDA above)
+    auto step = SWEEPQ_STEP_LAMBDA();
     auto tests_needed = [&]() -> bool {
         const unsigned long long bal = __ballot(flag);
         const unsigned cf = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
@@ -720,7 +641,7 @@ __global__ __launch_bounds__(SWEEPQ_THREADS, 1) void sweep_scd_qw_kernel(const S
     }
     __syncthreads(); // x image final
 
-    sweepqw_epilogue<NT>(a, xl, 16 * G, col_wg, (int)blockIdx.x);
+    sweepq_epilogue<NT, 0>(a, xl, 16 * G, col_wg, (int)blockIdx.x);
     {
         const long long totc = wave_sum_ll(counted);
         if (lane == 0 && totc) atomicAdd(a.sweeps, (unsigned long long)totc);

@@ -1110,15 +1110,20 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     if (!h->pack_ready)
         sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img, h->prec == NNLM_PREC_F64 ? 1 : 0);
     h->pack_ready = false;
-    // Launch policy.  A SIMD runs one wavefront (16 columns) of this sweep at full speed and a second one adds its whole time.  Up to
-    // one wavefront per SIMD: the plain form.  Between one and two (the benchmark's W half-step: 1250 for 1024): the persistent form,
-    // whose wavefronts share G = 5 .. 7 column groups per CU by the wrap-around rule -- ceil(G S / 4) sweeps of work per SIMD instead
-    // of 2 S.  Beyond: the plain form again (several balanced rounds).
+    // Launch policy.  A SIMD runs one wavefront (16 columns) of this sweep at full speed and a second one adds its whole time: the plain
+    // form costs ceil(groups / SIMDs) rounds of S sweeps.  The persistent form gives every CU G column groups, shared by its four
+    // wavefronts by the wrap-around rule -- ceil(G S / 4) sweeps per round of (one workgroup per CU) -- and is taken, with the G that
+    // costs least, whenever that is less: the benchmark's W half-step (1250 groups on 1024 SIMDs) G = 5, 1.25 S instead of 2 S;
+    // 2500 groups G = 10, 2.5 S instead of 3 S.  (Costs in quarters of S.)
     const int ngroups = (a.ncols - a.col0 + 15) / 16, simds = 4 * h->cus;
     int G = 0;
     if (ngroups > simds && a.max_iter >= 4) {
-        G = (ngroups + h->cus - 1) / h->cus;
-        if (G < 5 || G > SWEEPQ_WRAP_MAXG || sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, G) > (size_t)160 * 1024) G = 0;
+        long best = ((long)ngroups + simds - 1) / simds * 4; // the plain form
+        for (int g = 5; g <= SWEEPQ_WRAP_MAXG; g++) {
+            if (sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, g) > (size_t)160 * 1024) break;
+            const long wgs = ((long)ngroups + g - 1) / g, rounds = (wgs + h->cus - 1) / h->cus;
+            if (rounds * g < best) best = rounds * g, G = g;
+        }
     }
     if (G) nb = (ngroups + G - 1) / G;
     h->sweep_wgs = nb;
@@ -2642,6 +2647,12 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                     return rc;
                 }
                 spec.pending = true;
+                // Strict mode: errors64_kernel and the fp64 cross product both live on the fp64 matrix / vector pipe and serialise when they
+                // share the chip (0.98 ms for the pair against 0.40 + 0.60).  The error block therefore starts when the speculative cross
+                // product has finished streaming A -- beside the SWEEP, which is bound by dependent latency and leaves the pipe half idle.
+                // (round 5, bench.py --precision f64: 1.506 against 1.516-1.526 ms per step; the cross product 0.40 instead of 0.69 ms, the error
+                //  block 0.42 instead of 0.34)
+                if (h->prec == NNLM_PREC_F64 && !h->fused_nb) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
             } else
                 h->fused_nb = 0;
             CHK(errors_launch(h, h->stream_e, true, h->fused_nb, need_pen)); // reads W_i, H_i and the active sweep counter (then zeroes it)

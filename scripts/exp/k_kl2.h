@@ -121,8 +121,10 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
     auto wload = [&](const unsigned char *rowp, int e) -> f32x4 { return *(const f32x4 *)(rowp + (size_t)(e * KLT_THREADS + tid) * 16); };
 
     // ---- the scalar part of group G's step q, cut into stages that are issued between the chunks of the other group's pass A ----
-    // pre(G, q): what does not depend on the step's sums (coordinate, row sum, mask bit, Lee's reciprocal denominator)
-    auto pre = [&](auto Gc, int q) {
+    // A value that comes from LDS is first USED one stage (= one chunk of vector work) after its read was issued; what a stage computes
+    // is pinned where it is written (an opaque use), values still in flight are not (a pin on them would be a wait).
+    // pre-part (does not depend on the step's sums): coordinate, row sum, mask bit -> Lee's reciprocal denominator
+    auto pre_load = [&](auto Gc, int q) {
         constexpr int G = decltype(Gc)::value;
         const int cl = G * HC + lh;
         bool m = false;
@@ -130,15 +132,34 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
         doq_l[G] = run_l[G] && !m;
         xq_l[G] = xs[cl * k + q];
         sw_l[G] = sws[cl * k + q];
+    };
+    double den_[2] = {1.0, 1.0};
+    auto pre_den = [&](auto Gc) {
+        constexpr int G = decltype(Gc)::value;
         if (METHOD == 4) {
-            const double den = sw_l[G] + a.r0 * xq_l[G] + a.r1 * (S_l[G] - xq_l[G]) + a.r2; // :142
-            double rd = __builtin_amdgcn_rcp(den);
-            rd4_l[G] = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
+            den_[G] = sw_l[G] + a.r0 * xq_l[G] + a.r1 * (S_l[G] - xq_l[G]) + a.r2; // :142
+            double &d0 = den_[G];
+            asm volatile("" : "+v"(d0));
         }
+    };
+    auto pre_rcp = [&](auto Gc, int part) {
+        constexpr int G = decltype(Gc)::value;
+        if (METHOD == 4) {
+            if (part == 0) rd4_l[G] = __builtin_amdgcn_rcp(den_[G]);
+            else rd4_l[G] = __builtin_fma(__builtin_fma(-den_[G], rd4_l[G], 1.0), rd4_l[G], rd4_l[G]);
+            double &d0 = rd4_l[G];
+            asm volatile("" : "+v"(d0));
+        }
+    };
+    auto pre = [&](auto Gc, int q) { // (all at once: head of a sweep)
+        pre_load(Gc, q);
+        pre_den(Gc);
+        pre_rcp(Gc, 0);
+        pre_rcp(Gc, 1);
     };
     f32x4 rr_[2][NV]; // the eight wave totals of the lane's column, as read from LDS (stage 0)
     double sv_[NV];
-    constexpr int NST = 4;
+    constexpr int NST = 7;
     auto stage = [&](auto Gc, auto Sc, int q) {
         constexpr int G = decltype(Gc)::value, ST = decltype(Sc)::value;
         const int cl = G * HC + lh;
@@ -151,8 +172,11 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
             }
         } else if constexpr (ST == 1) {
 #pragma unroll
-            for (int v = 0; v < NV; v++)
+            for (int v = 0; v < NV; v++) {
                 sv_[v] = (double)(((rr_[0][v][0] + rr_[0][v][1]) + (rr_[0][v][2] + rr_[0][v][3])) + ((rr_[1][v][0] + rr_[1][v][1]) + (rr_[1][v][2] + rr_[1][v][3])));
+                double &s0 = sv_[v];
+                asm volatile("" : "+v"(s0));
+            }
         } else if constexpr (ST == 2) {
             coef_l[G] = 0.f;
             if (METHOD == 4) {
@@ -180,25 +204,21 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
                     if (wave == 0 && lane < HC) xs[cl * k + q] = tmp;
                 }
             }
+            float &cf = coef_l[G];
+            double &d0 = S_l[G];
+            asm volatile("" : "+v"(cf), "+v"(d0));
         } else if constexpr (ST == 3) {
             // the NEXT step's pre-part of this group (its coordinate is read now: wavefront 0 rewrites it a whole step from here)
-            const int qn = (q + 1 < k) ? q + 1 : 0;
-            pre(Gc, qn);
+            pre_load(Gc, (q + 1 < k) ? q + 1 : 0);
+        } else if constexpr (ST == 4) {
+            pre_den(Gc);
+        } else if constexpr (ST == 5) {
+            pre_rcp(Gc, 0);
+        } else if constexpr (ST == 6) {
+            pre_rcp(Gc, 1);
         }
     };
 
-    auto pin_stage = [&](auto Gc) { // opaque use of what a stage produced: the stage stays where it is written
-        constexpr int G = decltype(Gc)::value;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            f32x4 &r0 = rr_[0][v], &r1 = rr_[1][v];
-            double &s0 = sv_[v];
-            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(s0));
-        }
-        float &cf = coef_l[G];
-        double &d0 = S_l[G], &d1 = xq_l[G], &d2 = rd4_l[G], &d3 = sw_l[G];
-        asm volatile("" : "+v"(cf), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-    };
     // ---- pass A of group G on the row at rowp, the stages of the other group's scalar part between its chunks; ends with the wave
     // totals in red.  WAIT: pieces of this row may still be in flight (counted waits).  OG_ACTIVE: the other group has a step to finish.
     auto passA = [&](auto Gc, const unsigned char *rowp, bool wait_pieces, bool og_active, int og_q) {
@@ -209,8 +229,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
 #pragma unroll
             for (int v = 0; v < NV; v++) acc[c][v] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (og_active) stage(std::integral_constant<int, OG>{}, std::integral_constant<int, 0>{}, og_q);
-        pin_stage(std::integral_constant<int, OG>{});
-        f32x4 wq[2];
+        f32x4 wq[3];
         // piece e of the row has landed once at most (pieces requested - 1 - e) younger requests are outstanding; the wavefront requested
         // EPT4 pieces (last) or EPT4 - 1
         auto wait_piece = [&](auto ec) {
@@ -218,16 +237,22 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
             if (last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPT4 - 1 - e) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPT4 - 2 - e > 0 ? EPT4 - 2 - e : 0) : "memory");
         };
+        // (the row element of chunk e + 2 is requested while chunk e is processed: a one-column chunk is eight vector instructions, less
+        //  than an LDS round trip)
         if (wait_pieces) wait_piece(std::integral_constant<int, 0>{});
         wq[0] = wload(rowp, 0);
+        if (EPT4 > 1 && KLT_HAS(1)) {
+            if (wait_pieces) wait_piece(std::integral_constant<int, (EPT4 > 1 ? 1 : 0)>{});
+            wq[1] = wload(rowp, 1);
+        }
         klq_for<0, EPT4>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             if (KLT_HAS(e)) {
-                if (e + 1 < EPT4 && KLT_HAS(e + 1)) {
-                    if (wait_pieces) wait_piece(std::integral_constant<int, e + 1>{});
-                    wq[(e + 1) & 1] = wload(rowp, e + 1);
+                if (e + 2 < EPT4 && KLT_HAS(e + 2)) {
+                    if (wait_pieces) wait_piece(std::integral_constant<int, (e + 2 < EPT4 ? e + 2 : 0)>{});
+                    wq[(e + 2) % 3] = wload(rowp, e + 2);
                 }
-                const f32x4 w = wq[e & 1];
+                const f32x4 w = wq[e % 3];
 #pragma unroll
                 for (int c = 0; c < HC; c++) {
                     const f32x4 &yy = y[G * HC + c][e], &bq = b[G * HC + c][e];
@@ -256,8 +281,7 @@ __global__ __launch_bounds__(KLT_THREADS) void kl_tile2_kernel(const KlTileArgs 
             // fp64 instructions are covered by a chunk of both wavefronts' vector work)
             if constexpr (e + 1 < NST) {
                 if (og_active) stage(std::integral_constant<int, OG>{}, std::integral_constant<int, e + 1>{}, og_q);
-                pin_stage(std::integral_constant<int, OG>{});
-                __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);
             }
         });
         if (og_active) // (short rows: the stages that found no chunk to ride on)

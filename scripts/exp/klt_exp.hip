@@ -27,6 +27,18 @@ template <int EPT4, int C, int METHOD> static int launch0(const KlTileArgs &ta, 
     kl_tile_kernel<EPT4, C, METHOD, false><<<nb, KLT_THREADS, lds>>>(ta);
     return 0;
 }
+template <int EPT4, int C, int METHOD> static int launch3(const KlTileArgs &ta, size_t lds, int nb) // two 256-thread workgroups per CU, one row buffer
+{
+    CK(hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, METHOD, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kl_tile_kernel<EPT4, C, METHOD, true, 256><<<nb, 256, lds>>>(ta);
+    return 0;
+}
+template <int EPT4, int C, int METHOD> static int launch4(const KlTileArgs &ta, size_t lds, int nb) // 1024-thread workgroups: four wavefronts per SIMD
+{
+    CK(hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, METHOD, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kl_tile_kernel<EPT4, C, METHOD, false, 1024><<<nb, 1024, lds>>>(ta);
+    return 0;
+}
 template <int EPT4, int HC, int METHOD> static int launch2(const KlTileArgs &ta, size_t lds, int nb)
 {
     CK(hipFuncSetAttribute((const void *)kl_tile2_kernel<EPT4, HC, METHOD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -60,10 +72,15 @@ int main(int argc, char **argv)
     ta.Adata = dA; ta.lda = lda; ta.Yinit = dWh; ta.Yf = dY; ta.ldyf = (int)lda; ta.p = p; ta.ncols = ncols; ta.k = k; ta.X = dX; ta.Xout = dXo; ta.ldx = ldx;
     ta.colbase = 0; ta.ldo = ldx; ta.ocol0 = 0; ta.sumw = dS; ta.sumw_cols = nullptr; ta.ldsw = 0; ta.r0 = 0.0; ta.r1 = 0.0; ta.r2 = 0.0; ta.mask = nullptr; ta.mw = 1;
     ta.max_iter = sweeps; ta.rel_tol = -1.0; ta.op = nullptr; ta.op_mode = 0; ta.op_ld = 0; ta.sweeps = dSw;
-    const int e = (kl_tile_p4(p) + KLT_THREADS - 1) / KLT_THREADS;
-    const int C = e <= 2 ? 8 : (e <= 5 ? 4 : 2);
+    const int nt = variant == 3 ? 256 : (variant == 4 ? 1024 : KLT_THREADS);
+    const int e = (kl_tile_p4(p) + nt - 1) / nt;
+    const int C = variant == 4 ? 2 : (e <= 2 ? 8 : (e <= 5 ? 4 : (e <= 10 ? 2 : 1)));
     const int nb = (ncols + C - 1) / C;
-    const size_t lds = variant == 2 ? kl_tile2_lds_bytes(p, k, C) : kl_tile_lds_bytes(p, k, C, 0, 2);
+    const size_t lds = variant == 2 ? kl_tile2_lds_bytes(p, k, C) : kl_tile_lds_bytes(p, k, C, 0, variant == 3 ? 1 : 2, nt / 64);
+#if KLT_TIMING
+    unsigned long long *dT; CK(hipMalloc(&dT, (size_t)nb * 8 * 8)); CK(hipMemset(dT, 0, (size_t)nb * 8 * 8));
+    ta.tim = dT;
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f, tot = 0.f;
     for (int r = 0; r < reps; r++) {
@@ -71,7 +88,10 @@ int main(int argc, char **argv)
         int rc = 1;
 #define L0(E_, C_) if (e == E_) rc = (method == 4) ? launch0<E_, C_, 4>(ta, lds, nb) : launch0<E_, C_, 3>(ta, lds, nb);
 #define L2(E_, H_) if (e == E_) rc = (method == 4) ? launch2<E_, H_, 4>(ta, lds, nb) : launch2<E_, H_, 3>(ta, lds, nb);
+#define L3(E_, C_) if (e == E_) rc = (method == 4) ? launch3<E_, C_, 4>(ta, lds, nb) : launch3<E_, C_, 3>(ta, lds, nb);
         if (variant == 0) { L0(10, 2) L0(5, 4) L0(3, 4) L0(8, 2) }
+        else if (variant == 3) { L3(10, 2) L3(5, 4) L3(20, 1) }
+        else if (variant == 4) { if (e == 5) rc = launch4<5, 2, 4>(ta, lds, nb); if (e == 3) rc = launch4<3, 2, 4>(ta, lds, nb); }
         else { L2(10, 1) L2(5, 2) L2(3, 2) L2(8, 1) }
         if (rc) { printf("no instantiation for EPT4 = %d\n", e); return 1; }
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
@@ -118,7 +138,18 @@ int main(int argc, char **argv)
     unsigned long long sw = 0; CK(hipMemcpy(&sw, dSw, 8, hipMemcpyDeviceToHost));
     // checksum of the whole output (bit-identity between variants)
     double cs = 0.0; for (int q = 0; q < k; q++) for (int c = 0; c < ncols; c++) cs += Xo[(size_t)q * ldx + c] * (1.0 + 1e-3 * ((q * 31 + c) % 97));
+#if KLT_TIMING
+    {
+        std::vector<unsigned long long> T((size_t)nb * 8);
+        CK(hipMemcpy(T.data(), dT, T.size() * 8, hipMemcpyDeviceToHost));
+        double av[8] = {0};
+        for (int bq = 0; bq < nb; bq++) for (int i = 0; i < 8; i++) av[i] += (double)T[(size_t)bq * 8 + i];
+        double tot8 = 0; for (int i = 0; i < 8; i++) { av[i] /= nb; tot8 += av[i]; }
+        printf("   cycles per block (wavefront 0, last launch): loop/prologue %.0f | top %.0f | passA %.0f | totals %.0f | barrier %.0f | scalar %.0f | passB %.0f | epilogue %.0f | sum %.0f (%.1f per step)\n",
+               av[0], av[1], av[2], av[3], av[4], av[5], av[6], av[7], tot8, tot8 / (k * sweeps));
+    }
+#endif
     printf("p %d ncols %d k %d method %d variant %d exp %d EPT4 %d C %d lds %zu : best %.4f ms  mean %.4f ms  rel-err(6 cols) %.2e  sweeps %llu  checksum %.15e\n", p, ncols, k,
-           method, variant, (int)KLT_EXP, e, C, lds, best, tot / (reps > 1 ? reps - 1 : 1), worst, sw, cs);
+           method, variant, (int)KLT_EXP + 100 * (int)KLT_V, e, C, lds, best, tot / (reps > 1 ? reps - 1 : 1), worst, sw, cs);
     return 0;
 }

@@ -40,7 +40,9 @@ def _run(monkeypatch, cus, prec, A, k, W0, H0, Wm, Hm, reg, inner, tol, iters):
 
 
 @pytest.mark.parametrize("pname,prec,otol", [("f64", _lib.PREC_F64, 1e-9), ("f32", _lib.PREC_F32, 1e-4)])
-@pytest.mark.parametrize("cus,n,m", [(2, 150, 224), (3, 260, 330), (1, 70, 112)])  # G = 5 .. 7 each way (150 -> 5, 224 -> 7, 260 -> 6, 330 -> 7, 70 -> 5, 112 -> 7), ragged ends
+@pytest.mark.parametrize("cus,n,m", [(2, 150, 224), (3, 260, 330), (1, 70, 112),  # G = 5 .. 7 each way (150 -> 5, 224 -> 7, 260 -> 6, 330 -> 7, 70 -> 5, 112 -> 7), ragged ends
+                                     (1, 144, 160),   # round 5: 9 groups on one CU -> G = 9; 10 groups -> G = 5 in two rounds of workgroups
+                                     (2, 400, 300)])  # 25 groups on two CUs -> G = 7, four workgroups = two rounds; 19 groups -> G = 10
 @pytest.mark.parametrize("k,masks,inner,itol", [(50, False, 50, 1e-9), (7, True, 9, 1e-9), (64, True, 6, 1e-2), (33, False, 50, 1e-3)])
 def test_persistent_sweep_is_bit_identical_to_the_plain_form(monkeypatch, pname, prec, otol, cus, n, m, k, masks, inner, itol):
     rng = np.random.default_rng(1000 * k + n + cus)
@@ -72,3 +74,52 @@ def test_persistent_sweep_is_bit_identical_to_the_plain_form(monkeypatch, pname,
     assert relF(Ww, o["W"]) < otol and relF(Hw, o["H"]) < otol
     if pname == "f64" and itol < 1e-6:  # (sweep counts at a loose inner tolerance ride on rounding)
         assert sww == int(round(float(np.sum(o["average_epoch"])) * (n + m)))
+
+
+def test_launch_policy_picks_the_cheapest_form(monkeypatch):
+    """nnlm_get_info reports the form the last SCD sweep took: plain up to one wavefront per SIMD, the persistent form with the group
+    count per workgroup that costs least beyond (costs in quarter sweeps: plain ceil(groups / SIMDs) * 4, persistent rounds * G)."""
+    rng = np.random.default_rng(5)
+    k = 8
+    for cus, n, want in [(2, 128, (0, 4)), (2, 150, (1, 5)), (1, 144, (1, 9)), (1, 128, (0, 4)), (2, 400, (1, 7)), (2, 304, (1, 10))]:
+        A = rng.random((n, 40))
+        _lib.debug_set_cus(cus)
+        try:
+            h = nnlm_amd.Handle(0, _lib.PREC_F32)
+        finally:
+            _lib.debug_set_cus(0)
+        with h:
+            assert int(h.get_info("cus")) == cus and int(h.get_info("sweep_form_w")) == -1
+            h.set_matrix(A)
+            h.set_factors(k, rng.random((n, k)), rng.random((k, 40)))
+            h.half_step(0, [0, 0, 0], 10, 1e-9, 1)
+            h.sync()
+            assert (int(h.get_info("sweep_form_w")), int(h.get_info("sweep_groups_w"))) == want, (cus, n)
+
+
+def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd():
+    """the persistent form for any group count.  40000 columns (2500 groups of 16 on 1024 SIMDs: G = 10, 125 sweeps of
+    work per wavefront) must not cost more than 1.25 x per unit of work what 20000 columns cost (1250 groups: G = 5, 63 sweeps) -- the
+    plain form took three whole rounds of wavefronts for 2.44 rounds of work there."""
+    rng = np.random.default_rng(11)
+    k, m = 50, 256
+    per_col = {}
+    for n in (20000, 40000):
+        A = rng.random((n, m))
+        with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
+            h.set_matrix(A)
+            h.set_factors(k, 0.01 * rng.random((n, k)), 0.01 * rng.random((k, m)))
+            for _ in range(3):
+                h.half_step(0, [0, 0, 0], 50, -1.0, 1)  # (inner.rel.tol < 0: always 50 sweeps)
+            h.sync()
+            h.profile_reset()
+            h.profile_enable(True)
+            for _ in range(5):
+                h.half_step(0, [0, 0, 0], 50, -1.0, 1)
+            h.sync()
+            ms, cnt = h.profile_get("sweep_w")
+            h.profile_enable(False)
+            assert cnt == 5 and int(h.get_info("sweep_form_w")) == 1
+            per_col[n] = ms / cnt / n
+            print(f"sweep_w at {n} columns: {ms / cnt:.4f} ms, G = {int(h.get_info('sweep_groups_w'))}")
+    assert per_col[40000] <= 1.25 * per_col[20000], per_col
