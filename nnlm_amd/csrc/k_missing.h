@@ -673,19 +673,27 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
     if (!skip) {
         bool more = true; // rel = 1 + rel_tol > rel_tol
         for (; t < a.max_iter && more; t++) {
+            // Round 5: FIVE vector instructions per step.  Lane q alone takes its coordinate's step, under an execution mask of that one lane:
+            //     s_mov_b64  exec = {q}
+            //     v_max_f64  xd = max(-x, -nu)      (= max(0, x - nu) - x without the canonicalisation of fmax())
+            //     v_add_f64  x += xd
+            //     s_mov_b64  exec = all
+            // then the delta reaches every lane's gradient as before (2 v_readlane_b32 -> SGPR pair, v_fma_f64 nu += d * Gs[q]).  xd is ONE
+            // register through the sweep: a coordinate moves once per sweep, so at its end lane q still holds the delta of ITS step (masked
+            // coordinates their 0) -- what the two v_writelane_b32 of rounds 2-4 assembled.  The scalar moves go to the scalar unit, which
+            // idles beside this kernel; same operations on the same numbers: results are bit-identical.
+            const double x0 = x;
             double xd = 0.0;
             int kk = k;
             asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
             auto step = [&](const int q) {
-                double dd;
-                asm("v_max_f64 %0, -%1, -%2" : "=v"(dd) : "v"(x), "v"(nu)); // = max(0, x - nu) - x without the canonicalisation of fmax()
-                int2 dp = __builtin_bit_cast(int2, dd);
+                unsigned long long sv;
+                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %4\n\tv_max_f64 %0, -%1, -%3\n\tv_add_f64 %1, %1, %0\n\ts_mov_b64 exec, %2"
+                             : "+v"(xd), "+v"(x), "=&s"(sv)
+                             : "v"(nu), "s"(1ull << q));
+                int2 dp = __builtin_bit_cast(int2, xd);
                 const int dlo = __builtin_amdgcn_readlane(dp.x, q), dhi = __builtin_amdgcn_readlane(dp.y, q);
                 nu = __builtin_fma(__builtin_bit_cast(double, int2{dlo, dhi}), gs[q], nu);
-                int2 xp = __builtin_bit_cast(int2, xd);
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xp.x) : "s"(dlo), "n"(q));
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xp.y) : "s"(dhi), "n"(q));
-                xd = __builtin_bit_cast(double, xp);
             };
 #pragma unroll
             for (int c = 0; c < NKQ; c++) {
@@ -699,9 +707,7 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
                             if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
                 }
             }
-            const double xn = x + xd;
-            const bool big = 2 * fabs(xd) > a.rel_tol * (xn + x + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
-            x = xn;
+            const bool big = 2 * fabs(xd) > a.rel_tol * (x + x0 + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
             more = __ballot(big && lv) != 0ull || 0.0 > a.rel_tol;
         }
     }

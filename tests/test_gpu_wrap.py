@@ -81,7 +81,7 @@ def test_launch_policy_picks_the_cheapest_form(monkeypatch):
     count per workgroup that costs least beyond (costs in quarter sweeps: plain ceil(groups / SIMDs) * 4, persistent rounds * G)."""
     rng = np.random.default_rng(5)
     k = 8
-    for cus, n, want in [(2, 128, (0, 4)), (2, 150, (1, 5)), (1, 144, (1, 9)), (1, 128, (0, 4)), (2, 400, (1, 7)), (2, 304, (1, 10))]:
+    for cus, n, want in [(2, 128, (0, 4)), (2, 150, (1, 5)), (1, 144, (1, 9)), (1, 128, (0, 4)), (2, 400, (1, 7)), (2, 304, (1, 5)), (2, 280, (1, 9))]:
         A = rng.random((n, 40))
         _lib.debug_set_cus(cus)
         try:
