@@ -5,6 +5,7 @@
 // plain device kernel.  Check: the first and last columns against an fp64 host restatement of lee_kl_update / scd_kl_update.
 #include "../../nnlm_amd/csrc/k_kl.h"
 #include "k_kl2.h"
+#include "k_kl3.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,12 @@ template <int EPT4, int C, int METHOD> static int launch4(const KlTileArgs &ta, 
 {
     CK(hipFuncSetAttribute((const void *)kl_tile_kernel<EPT4, C, METHOD, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kl_tile_kernel<EPT4, C, METHOD, false, 1024><<<nb, 1024, lds>>>(ta);
+    return 0;
+}
+template <int EPT4, int C, int METHOD> static int launch5(const KlTileArgs &ta, size_t lds, int nb) // one vector pass per step (k_kl3.h)
+{
+    CK(hipFuncSetAttribute((const void *)kl_tile3_kernel<EPT4, C, METHOD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kl_tile3_kernel<EPT4, C, METHOD><<<nb, KLT_THREADS, lds>>>(ta);
     return 0;
 }
 template <int EPT4, int HC, int METHOD> static int launch2(const KlTileArgs &ta, size_t lds, int nb)
@@ -91,6 +98,8 @@ int main(int argc, char **argv)
 #define L3(E_, C_) if (e == E_) rc = (method == 4) ? launch3<E_, C_, 4>(ta, lds, nb) : launch3<E_, C_, 3>(ta, lds, nb);
         if (variant == 0) { L0(10, 2) L0(5, 4) L0(3, 4) L0(8, 2) }
         else if (variant == 3) { L3(10, 2) L3(5, 4) L3(20, 1) }
+#define L5(E_, C_) if (e == E_) rc = (method == 4) ? launch5<E_, C_, 4>(ta, lds, nb) : launch5<E_, C_, 3>(ta, lds, nb);
+        else if (variant == 5) { L5(10, 2) L5(5, 4) L5(3, 4) L5(8, 2) }
         else if (variant == 4) { if (e == 5) rc = launch4<5, 2, 4>(ta, lds, nb); if (e == 3) rc = launch4<3, 2, 4>(ta, lds, nb); }
         else { L2(10, 1) L2(5, 2) L2(3, 2) L2(8, 1) }
         if (rc) { printf("no instantiation for EPT4 = %d\n", e); return 1; }
