@@ -198,6 +198,10 @@ int nnlm_debug_exchange(nnlm_handle **handles, int nranks, int which, int stage)
 /* Test hook: handles created from now on plan their launches as if the device had `cus` compute units (0 = the device's own
  * count) -- small problems then take the launch forms large ones take on the real device (persistent SCD sweep). */
 int nnlm_debug_set_cus(int cus);
+/* Test hook: the matrix-sized workspaces of the KL solvers (starting states of all columns, transposed copy of A, streaming scratch)
+ * "do not fit" when they exceed `bytes` (0 = no limit): the half-step then takes its smaller-footprint path -- the streaming kernel
+ * over column chunks -- exactly as it does when hipMalloc itself says no. */
+int nnlm_debug_alloc_limit(size_t bytes);
 /* Facts about the handle's last launches, for bench.py's kernel attribution: key = "cus" (compute units the launch policy
  * counts), "sweep_form_w" / "sweep_form_h" (SCD sweep of the last W / H half-step: 0 plain sweep_scd_q_kernel, 1 persistent
  * sweep_scd_qw_kernel, -1 none yet), "sweep_groups_w" / "sweep_groups_h" (column groups per workgroup of that launch). */

@@ -29,7 +29,7 @@ EXPORTS = [
     "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
     "nnlm_shard_range", "nnlm_shard_cols", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
-    "nnlm_comm_set_form", "nnlm_debug_set_cus", "nnlm_get_info",
+    "nnlm_comm_set_form", "nnlm_debug_set_cus", "nnlm_get_info", "nnlm_debug_alloc_limit",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     lib.nnlm_comm_set_form.argtypes = [vp, C.c_int]
     lib.nnlm_debug_set_cus.restype = C.c_int
     lib.nnlm_debug_set_cus.argtypes = [C.c_int]
+    lib.nnlm_debug_alloc_limit.restype = C.c_int
+    lib.nnlm_debug_alloc_limit.argtypes = [C.c_size_t]
     lib.nnlm_get_info.restype = C.c_int
     lib.nnlm_get_info.argtypes = [vp, C.c_char_p, dp]
     _lib = lib
@@ -398,6 +400,11 @@ def debug_exchange(handles, which, stage):
 def debug_set_cus(cus: int):
     """Test hook: handles created from now on plan their launches for `cus` compute units (0 = the device's own count)."""
     _check(load().nnlm_debug_set_cus(int(cus)))
+
+
+def debug_alloc_limit(nbytes: int):
+    """Test hook: matrix-sized KL workspaces beyond `nbytes` "do not fit" (0 = no limit) -> the streaming path over column chunks."""
+    _check(load().nnlm_debug_alloc_limit(int(nbytes)))
 
 
 def comm_unique_id() -> bytes:

@@ -291,6 +291,27 @@ extern "C" unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace)
 }
 
 static int g_debug_cus = 0; // nnlm_debug_set_cus: compute units the launch policies of new handles count (0 = the device's)
+static size_t g_debug_alloc_limit = 0; // nnlm_debug_alloc_limit: matrix-sized KL workspaces beyond this many bytes "do not fit" (0 = no limit)
+
+// Matrix-sized workspaces of the KL solvers (starting states of all columns, transposed copy of A, streaming scratch): the callers have
+// a smaller-footprint path when one of them cannot be had, so a failure here is an answer, not an error.
+static hipError_t big_malloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (g_debug_alloc_limit && bytes > g_debug_alloc_limit) return hipErrorOutOfMemory;
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+    }
+    return e;
+}
+
+extern "C" int nnlm_debug_alloc_limit(size_t bytes)
+{
+    g_debug_alloc_limit = bytes;
+    return NNLM_OK;
+}
 
 extern "C" int nnlm_debug_set_cus(int cus)
 {
@@ -954,10 +975,15 @@ static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
 static bool generic_rank(const nnlm_handle *h) { return h->k > NNLM_KQ_MAX; }
 
 // contraction-contiguous copy of A ([npad][mpad], element type of the mode), made once per matrix
-static int ensure_AT(nnlm_handle *h)
+// soft: a copy that does not fit is reported as NNLM_ERR_UNSUPPORTED without an error message (the KL solvers then take their streaming path)
+static int ensure_AT(nnlm_handle *h, bool soft = false)
 {
     if (h->AT) return NNLM_OK;
-    HIPCHK(h, hipMalloc(&h->AT, (size_t)h->npad * h->mpad * esize(h) + 4096));
+    const size_t bytes = (size_t)h->npad * h->mpad * esize(h) + 4096;
+    if (soft) {
+        if (big_malloc(&h->AT, bytes) != hipSuccess) return NNLM_ERR_UNSUPPORTED;
+    } else
+        HIPCHK(h, hipMalloc(&h->AT, bytes));
     dim3 grid(h->npad / 64, h->mpad / 64);
     if (h->prec == NNLM_PREC_F64) transpose_kernel<double><<<grid, 256, 0, h->stream>>>((const double *)h->A, h->npad, (double *)h->AT, h->mpad);
     else transpose_kernel<float><<<grid, 256, 0, h->stream>>>((const float *)h->A, h->npad, (float *)h->AT, h->mpad);
@@ -1532,12 +1558,24 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     }
     {
     ProfScope ps(h, which == 1 ? P_SWEEP_H : P_SWEEP_W);
-    if (h->prec == NNLM_PREC_F32 && kl_tile_fits(a.p, h->k, a.mask ? h->MW : 0)) {
+    // The register-resident kernels start from the states y = Yt^T x of ALL columns (one GEMM into a matrix-sized buffer) and read
+    // contraction-contiguous data (a transposed copy of A for the W half-step): one to two more copies of the matrix in HBM.  Where they
+    // cannot be had, the streaming kernel takes the half-step in column chunks, with whatever scratch it can get (strided reads of A for
+    // the W half-step: slow, and the reference's arithmetic either way) -- an allocation that fails here is not an error.
+    bool tile_path = h->prec == NNLM_PREC_F32 && kl_tile_fits(a.p, h->k, a.mask ? h->MW : 0);
+    bool reg64_path = h->prec == NNLM_PREC_F64 && !generic_rank(h) && kl64_fits(a.p, h->k);
+    if (tile_path && !h->What && big_malloc((void **)&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096) != hipSuccess) tile_path = false;
+    if (reg64_path && !h->What64 && big_malloc((void **)&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096) != hipSuccess) reg64_path = false;
+    if ((tile_path || reg64_path) && which == 0) {
+        const int rc = ensure_AT(h, true);
+        if (rc == NNLM_ERR_UNSUPPORTED) tile_path = reg64_path = false;
+        else if (rc != NNLM_OK) return rc;
+    }
+    if (tile_path) {
         // ---- fp32-operand mode: register-resident state, rows of the fixed factor staged through LDS (kl_tile_kernel) ----
         KlTileArgs ta;
         const size_t cnt = (size_t)h->KP * h->mpad; // fp32 [KP][mpad] copy of H (fixed factor of the W half-step, operand of the GEMM below)
         factor_to_f32_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, h->stream>>>(h->H64, cnt, h->Hkq);
-        if (!h->What) HIPCHK(h, hipMalloc(&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096));
         if (!h->klsw) HIPCHK(h, hipMalloc(&h->klsw, (size_t)h->KP * 8));
         // starting state vectors y = Yt^T x of ALL columns as one GEMM, in the layout the solver reads: [column][contraction]
         const int k2 = round_up_i(h->k, 2);
@@ -1604,10 +1642,9 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ta.op_ld = a.op_ld;
         ta.sweeps = a.sweeps;
         launch_kl_tile(method, ta, h->stream);
-    } else if (h->prec == NNLM_PREC_F64 && !generic_rank(h) && kl64_fits(a.p, h->k)) {
+    } else if (reg64_path) {
         // ---- strict fp64 mode: register-resident fp64 state, the row of the fixed factor parked in LDS between the passes ----
         Kl64Args ka;
-        if (!h->What64) HIPCHK(h, hipMalloc(&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096));
         if (!h->klsw) HIPCHK(h, hipMalloc(&h->klsw, (size_t)h->KP * 8));
         const int k4 = round_up_i(h->k, 4);
         // (multi-GPU: only the column tiles of this rank's shard -- its first column is a multiple of 256)
@@ -1670,18 +1707,36 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ka.sweeps = a.sweeps;
         launch_kl64(method, ka, h->stream);
     } else {
-        // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel) ----
-        const size_t need = (size_t)ncols_all * 2 * ld_con * esize(h);
-        if (h->klst_bytes < need) {
-            hipFree(h->klst);
-            h->klst = nullptr;
-            h->klst_bytes = 0;
-            HIPCHK(h, hipMalloc(&h->klst, need));
-            h->klst_bytes = need;
+        // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel), `chunk` columns at a
+        // time: the whole range when the scratch for it can be had (two vectors per column), otherwise as many as fit
+        const size_t per_col = (size_t)2 * ld_con * esize(h);
+        const int range = a.ncols > a.col0 ? a.ncols - a.col0 : 0;
+        int chunk = range;
+        if (range > 0 && h->klst_bytes < (size_t)range * per_col) {
+            if (h->klst_bytes >= (size_t)64 * per_col && h->klst_bytes / per_col >= (size_t)range / 8) // (a scratch of an earlier, tighter time: keep it)
+                chunk = (int)(h->klst_bytes / per_col);
+            else {
+                hipFree(h->klst);
+                h->klst = nullptr;
+                h->klst_bytes = 0;
+                for (;; chunk = (chunk + 1) / 2) {
+                    if (big_malloc(&h->klst, (size_t)chunk * per_col) == hipSuccess) break;
+                    if (chunk <= 64) return fail(h, NNLM_ERR_HIP, "KL solver: no scratch for even %d columns (%zu bytes)", chunk, (size_t)chunk * per_col);
+                }
+                h->klst_bytes = (size_t)chunk * per_col;
+            }
         }
-        const int rcs = (h->prec == NNLM_PREC_F64) ? launch_kl_stream<double>(h, method, a, h->MW, h->klst, (size_t)ld_con, h->stream)
-                                                   : launch_kl_stream<float>(h, method, a, h->MW, h->klst, (size_t)ld_con, h->stream);
-        if (rcs != NNLM_OK) return rcs;
+        const int col_end = a.ncols;
+        for (int c0 = a.col0; c0 < col_end; c0 += chunk) {
+            KlArgs ac = a;
+            ac.col0 = c0;
+            ac.ncols = (c0 + chunk < col_end) ? c0 + chunk : col_end;
+            // (the kernel addresses the scratch by absolute column: the chunk's slots start at its first column)
+            char *st = (char *)h->klst - (size_t)c0 * per_col;
+            const int rcs = (h->prec == NNLM_PREC_F64) ? launch_kl_stream<double>(h, method, ac, h->MW, st, (size_t)ld_con, h->stream)
+                                                       : launch_kl_stream<float>(h, method, ac, h->MW, st, (size_t)ld_con, h->stream);
+            if (rcs != NNLM_OK) return rcs;
+        }
     }
     }
     LAUNCHCHK(h);

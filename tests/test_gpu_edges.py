@@ -173,3 +173,39 @@ def test_na_logical_mask_entries_are_masked(monkeypatch, env):
                          C.byref(nt), C.byref(ni), C.byref(wd), None)
     assert rc == 0
     assert np.array_equal(Wo, Wo2) and np.array_equal(Ho, Ho2)
+
+
+@pytest.mark.parametrize("pname,prec,tol_self,tol", [("f64", _lib.PREC_F64, 1e-10, 1e-9), ("f32", _lib.PREC_F32, 2e-5, 1e-4)])
+@pytest.mark.parametrize("method", [3, 4])
+@pytest.mark.parametrize("na", [False, True])
+def test_kl_half_steps_take_the_streaming_path_when_their_workspaces_do_not_fit(pname, prec, tol_self, tol, method, na):
+    """the register-resident KL kernels keep one to two more copies of the matrix in HBM (starting states of all columns, a
+    transposed copy of A for the W half-step) and used to fail with NNLM_ERR_HIP when one of them could not be allocated.  Now an allocation
+    that fails sends the half-step to kl_stream_kernel over column CHUNKS with whatever scratch can be had.  nnlm_debug_alloc_limit makes
+    workspaces beyond 1 MB "not fit": What (1.5 / 3 MB) and AT fail, the full streaming scratch (4 - 9 MB) fails, a chunk of ~60 columns
+    fits -- eight launches per half-step.  Same factors as the roomy run (same reference arithmetic, another summation order) and as the
+    oracle; the handle keeps working when the limit is lifted."""
+    rng, A, W0, H0 = _planted(900 + method + (7 if na else 0), 700, 500, 6)
+    if na:
+        A[rng.random(A.shape) < 0.12] = np.nan
+    reg = [0.01, 0.005, 0.02]
+    inner = 2 if method == 3 else 1
+
+    def run():
+        with nnlm_amd.Handle(0, prec) as h:
+            h.set_matrix(A)
+            h.set_factors(6, W0, H0)
+            h.iterate(2, reg, reg, inner, 1e-9, method)
+            W, H = h.get_factors()
+            return W, H, h.take_sweeps()
+
+    W1, H1, s1 = run()
+    _lib.debug_alloc_limit(1 << 20)
+    try:
+        W2, H2, s2 = run()
+    finally:
+        _lib.debug_alloc_limit(0)
+    assert relF(W2, W1) < tol_self and relF(H2, H1) < tol_self, (relF(W2, W1), relF(H2, H1))
+    assert s1 == s2
+    o = ref.c_nnmf(A, 6, W0, H0, None, None, reg, reg, 2, -1.0, 0, 0, False, inner, 1e-9, method, 2)
+    assert relF(W2, o["W"]) < tol and relF(H2, o["H"]) < tol, (relF(W2, o["W"]), relF(H2, o["H"]))
