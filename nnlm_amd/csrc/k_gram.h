@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const double *__restr
         __syncthreads();
         if (threadIdx.x == 0) {
             mx = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
-            if (mx > 0.0f) atomicMax(maxw, __float_as_uint(mx));
+            // (the word only grows: a workgroup whose maximum is not above what is already there has nothing to add -- after the first
+            //  few workgroups hardly any atomic is left)
+            if (mx > 0.0f && __float_as_uint(mx) > __hip_atomic_load(maxw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxw, __float_as_uint(mx));
         }
     }
     if (!live) return;
