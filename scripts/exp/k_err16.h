@@ -1,6 +1,7 @@
 // k_err16.h -- err16_kernel: the fp32-operand mode's error block as a kernel of its own on the fp16 matrix cores, meant to run BESIDE the
 // sweep of the speculative W half-step instead of riding in its cross product (experiment of round 5, measured and NOT taken).
-// Wired into nnlm_run behind a switch (git history: commit "err16 experiment"), bench.py at config 2, same final mse:
+// Wired into nnlm_run behind a temporary switch (errors_launch: split copies W16c / H16c from the fused path's preparation, the plain cross
+// product on the main stream, this kernel on the error stream after ev_xdone, grid (npad / 64, S); not kept), bench.py at config 2, same final mse:
 //     fused cross product (xprod16_err_kernel, production)            0.686 ms per step   1395 it/s
 //     err16_kernel on the error stream after the cross product, S = 4 0.737               1301        (S = 2: 0.757, 8: 0.740, 16: 0.743)
 // The kernel needs ~0.3 ms beside the sweep (the host waits for it: 0.36 ms from the cross product's end to the sums) where the fused
