@@ -574,7 +574,9 @@ __device__ static inline float kl_wave_total(float v)
 #define KLT_PIN 1 // 1: keep every chunk's arithmetic between its own row request and the next one (see pass A)
 #endif
 #ifndef KLT_EXP
-#define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests, 4 no pass B, 8 no pass A
+#define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests.  (Rounds 2-4 also had
+                  // 4 "no pass B" and 8 "no pass A": without pass B the state never changes and the compiler hoists every reciprocal out of the
+                  // coordinate loop, without pass A nothing reads the state and pass B is dead code -- they did not measure what they said.)
 #endif
 // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the vector-memory queue, i.e. wait for the
 // row prefetch (LDS-DMA) at every coordinate step.  Each wavefront reads back only LDS slots its own LDS-DMA wrote, after its
@@ -607,10 +609,9 @@ __device__ static inline void klt_wait_vm(int n)
 // ONEBUF (contractions of 20481 .. ~40400: a row is up to 158 KB, one buffer is all the LDS holds): piece e of the NEXT row is
 // requested into its slot right after pass B has read piece e of this row back, and pass A waits for piece e with a counted
 // s_waitcnt -- the scheme of kl_reg64_kernel.  (Two buffers otherwise: the next row is requested during pass A.)
-// NT = threads of the workgroup: 512 (one workgroup per CU, two of its wavefronts per SIMD) or 256 (TWO independent workgroups per CU, one
-// wavefront of each per SIMD: while one workgroup reduces, waits at its barrier, runs its scalar part or loads its next columns, the other
-// one's vector passes have the SIMDs -- what the lock step of a single workgroup's eight wavefronts cannot give; its LDS request must
-// stay at or below 80 KB, i.e. one row buffer for contractions beyond ~5000).
+// NT = threads of the workgroup.  The library instantiates 512 only (one workgroup per CU, two of its wavefronts per SIMD).  256 (TWO
+// independent workgroups per CU, one wavefront of each per SIMD, one row buffer: LDS <= 80 KB) and 1024 (four wavefronts per SIMD at
+// 128 registers) are the forms scripts/exp/klt_exp.hip measured in round 5 -- same throughput / 40 % slower.
 template <int EPT4, int C, int METHOD, bool ONEBUF = false, int NT = KLT_THREADS>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl_tile_kernel(const KlTileArgs a)
 {
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
                     if (!ONEBUF) issue_piece(qn, nbuf, e);
                     const f32x4 w = wq[e & 1];
 #pragma unroll
-                    for (int c = 0; c < ((KLT_EXP & 8) ? 0 : C); c++) {
+                    for (int c = 0; c < C; c++) {
                         f32x4 r;
                         r[0] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][0]));
                         r[1] = __builtin_amdgcn_rcpf(__builtin_fabsf(y[c][e][1]));
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
                         if (KLT_HAS(e)) wb[e] = wload(e);
                 }
 #pragma unroll
-                for (int e = 0; e < ((KLT_EXP & 4) ? 0 : EPT4); e++) {
+                for (int e = 0; e < EPT4; e++) {
                     if (KLT_HAS(e)) { // wave-uniform
                         if (e + PD < EPT4 && KLT_HAS(e + PD)) wb[(e + PD) % (PD + 1)] = wload(e + PD);
                         const f32x4 w = wb[e % (PD + 1)];

@@ -41,10 +41,10 @@ __device__ static inline void split16(float v, float scale, _Float16 &hi, _Float
 }
 
 // scal_exp[0] = eA (written by the host), scal_exp[1] = eY (written by factor16_kernel's companion absmax pass)
-// NBUF: LDS stage buffers.  3 (default): two stages in flight while one is consumed, 144 KB at KP = 64 -- the block owns its CU.
-// 2: one stage in flight, 96 KB -- leaves room for a workgroup of the SCD sweep (57 KB) on the same CU: the form the pipelined
-// schedule runs while sweeps are in flight.
-template <int NKQ, int EXP = 0, int NBUF = XPROD_NBUF>
+// Ring of XPROD_NBUF = 3 LDS stage buffers: two stages in flight while one is consumed, 144 KB at KP = 64 -- the block owns its CU.
+// (A two-buffer, 96 KB form that leaves room for a workgroup of the SCD sweep on the same CU was measured in round 4 -- DESIGN.md
+// section 6: co-residency hides 0.07 of 0.26 ms -- and is not kept.)
+template <int NKQ, int EXP = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_t *__restrict__ A16, int lda,   // lda: elements per column
                                                                    const uint32_t *__restrict__ Y16, int ldy,   // ldy: elements per row
                                                                    double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -95,17 +95,16 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
     };
     const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
     if (st0 < st1) issue(st0, 0);
-    if (NBUF > 2 && st0 + 1 < st1) issue(st0 + 1, 1);
+    constexpr int NBUF = XPROD_NBUF;
+    static_assert(NBUF == 3, "two stages in flight while one is consumed");
+    if (st0 + 1 < st1) issue(st0 + 1, 1);
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
         unsigned char *buf = smem + ((st - st0) % NBUF) * BUF;
-        wait_vmcnt((NBUF > 2 && st + 1 < st1) ? per_stage : 0);
+        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (NBUF > 2) {
-            if (st + 2 < st1) issue(st + 2, (st + 2 - st0) % NBUF);
-        } else if (st + 1 < st1) // (the buffer stage st - 1 was read from: every wavefront has passed the barrier)
-            issue(st + 1, (st + 1 - st0) % NBUF);
+        if (st + 2 < st1) issue(st + 2, (st + 2 - st0) % NBUF);
         if (EXP & 2) continue;
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks per stage; lane (l15, lg) holds elements 32*c2 + 8*lg .. +7
