@@ -90,3 +90,24 @@ def test_plain_invocation_reaches_the_gpu_call_and_fails_loudly_without_one(gpu_
     assert p.returncode not in (0, 2), (p.returncode, p.stderr[-400:])
     assert "no HIP device" in p.stderr and "exited with" in p.stderr, p.stderr[-600:]
     assert p.stdout.strip() == ""
+
+
+def test_roofline_block_is_the_dominant_kernel_with_a_real_bound():
+    """The contract reserves `roofline` for the dominant kernel and its HBM / MFMA bound.  The two half-steps' plain cross products are
+    launches of one kernel (the first row of rocprofv3's summary), so they rank as one class: with the per-kernel times of a committed
+    bench line (profiles/r05_cfg2_bench_steps20.json) the block must be the A-streaming cross product, HBM bound, at achieved =
+    algorithmic bytes / average launch time, and the persistent sweep (no roofline: a loop-carried recurrence) must be the secondary."""
+    bench = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_cfg2_bench_steps20.json")))
+    kern = d["kernels"]
+    roof, sec, blocks, shares = bench.analyse(bench.CONFIGS[2], 2, kern, 20000, 10000, 50, 4, 1, {"sweep_w": 1, "sweep_h": 0})
+    assert roof["bound"] == "hbm" and "xprod16_tn_kernel" in roof["kernel"] and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    n_l = kern["xprod_h"]["launches"] + kern["xprod_w"]["launches"]
+    ms = (kern["xprod_h"]["total_ms"] + kern["xprod_w"]["total_ms"]) / n_l
+    by = ((20000 * 10000 * 4 + 50 * 20000 * 4 + 50 * 10000 * 8) * kern["xprod_h"]["launches"] +
+          (20000 * 10000 * 4 + 50 * 10000 * 4 + 50 * 20000 * 8) * kern["xprod_w"]["launches"]) / n_l
+    assert abs(roof["achieved"] - by / (ms * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    assert 0.5 < roof["frac"] < 0.8 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["traffic"] is not None and 0.9 < roof["traffic"] / by < 1.3  # (PMC bytes per launch from the committed summaries)
+    assert sec["bound"] == "latency" and "sweep_scd_qw_kernel" in sec["kernel"]
+    assert {"xprod_h", "xprod_w", "xprod_w_err", "sweep_h", "sweep_w"} <= set(blocks)
