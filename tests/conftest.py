@@ -33,3 +33,18 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _test_cus():
+    """NNLM_TEST_CUS=n: the whole run plans its launches as if the device had n compute units (nnlm_debug_set_cus, a test hook of the C
+    ABI) -- the deep fuzz runs of DESIGN.md section 2 put small random shapes through the persistent form of the SCD sweep this way.
+    (Rounds 1-4 had the library read NNLM_DEBUG_CUS itself.)"""
+    n = int(os.environ.get("NNLM_TEST_CUS", "0") or 0)
+    if n > 0 and _has_gpu():
+        from nnlm_amd import _lib
+        _lib.debug_set_cus(n)
+    yield
+    if n > 0 and _has_gpu():
+        from nnlm_amd import _lib
+        _lib.debug_set_cus(0)

@@ -123,3 +123,31 @@ def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd():
             per_col[n] = ms / cnt / n
             print(f"sweep_w at {n} columns: {ms / cnt:.4f} ms, G = {int(h.get_info('sweep_groups_w'))}")
     assert per_col[40000] <= 1.25 * per_col[20000], per_col
+
+
+@pytest.mark.parametrize("pname,prec,tol", [("f64", _lib.PREC_F64, 1e-9), ("f32", _lib.PREC_F32, 1e-4)])
+def test_forty_thousand_columns_on_the_real_device_match_the_oracle(pname, prec, tol):
+    """The launch forms the real CU count produces beyond two wavefronts per SIMD, against the oracle: 40000 columns (2500 groups: the
+    persistent form in two rounds of workgroups) and 29000 (1813 groups: the plain form in two rounds of wavefronts), one W half-step of
+    50 sweeps each, both arithmetic modes; sweep counts exact in the strict mode."""
+    rng = np.random.default_rng(23)
+    k, m = 50, 192
+    for n, want_form in ((40000, 1), (29000, 0)):
+        Wp, Hp = rng.random((n, k + 2)) ** 2 + 0.05, rng.random((k + 2, m)) ** 2 + 0.05
+        A = Wp @ Hp / (k + 2) * 4 + 0.02 * rng.random((n, m)) + 0.01
+        sc = 2.0 / np.sqrt(k + 2)
+        W0, H0 = Wp[:, :k] * sc * (0.7 + 0.6 * rng.random((n, k))), Hp[:k, :] * sc * (0.7 + 0.6 * rng.random((k, m)))
+        reg = [0.01, 0.0, 0.005]
+        with nnlm_amd.Handle(0, prec) as h:
+            h.set_matrix(A)
+            h.set_factors(k, W0, H0)
+            h.half_step(0, reg, 50, 1e-9, 1)
+            W, _ = h.get_factors()
+            sw = h.take_sweeps()
+            if int(h.get_info("cus")) == 256:
+                assert int(h.get_info("sweep_form_w")) == want_form, (n, h.get_info("sweep_groups_w"))
+        # the W half-step is update(Wt, H, A^T) (src/nnmf.cpp:131): Wt k x n solved, H the fixed factor, contraction over the m columns of A
+        Wt, sweeps = ref.update(W0.T.copy(), H0, np.ascontiguousarray(A.T), None, reg, 50, 1e-9, 1)
+        assert relF(W, Wt.T) < tol, (n, relF(W, Wt.T))
+        if pname == "f64":
+            assert sw == sweeps, (n, sw, sweeps)
