@@ -7,4 +7,4 @@ python -m pytest tests/test_gpu_wrap.py -x -q -m gpu -k "forty" 2>&1 | grep -v "
 NNLM_FUZZ_SEEDS=300 timeout 3000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -3 > gpurun_out/r05/k_fuzz300.log
 NNLM_TEST_CUS=3 NNLM_FUZZ_SEEDS=60 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -3 > gpurun_out/r05/k_fuzz60_cus3.log
 NNLM_TEST_CUS=7 NNLM_FUZZ_SEEDS=60 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -3 > gpurun_out/r05/k_fuzz60_cus7.log
-tail -3 gpurun_out/r05/k_tests_wrap.log gpurun_out/r05/k_fuzz300.log gpurun_out/r05/k_fuzz60_cus3.log gpurun_out/r05/k_fuzz60_cus7.log
+for f in gpurun_out/r05/k_*.log; do tail -n 3 "$f"; done
