@@ -20,6 +20,7 @@
 #include "common.h"
 #include "k_xprod.h"
 #include "k_gram.h"
+#include <type_traits>
 
 typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
 #define XPROD16_LO_SCALE 2048.0f // 2^11
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
         wait_vmcnt((st + 1 < st1) ? per_stage : 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st + 2 < st1) issue(st + 2, (st + 2 - st0) % NBUF);
+        const bool late = (EXP & 8) && wave >= XPROD_WAVES / 2; // (experiment: half of the wavefronts issue behind their MFMA phase)
+        if (st + 2 < st1 && !late) issue(st + 2, (st + 2 - st0) % NBUF);
         if (EXP & 2) continue;
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks per stage; lane (l15, lg) holds elements 32*c2 + 8*lg .. +7
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
                 accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh[nt], accx[nt], 0, 0, 0);
             }
         }
+        if (st + 2 < st1 && late) issue(st + 2, (st + 2 - st0) % NBUF);
         if (++since_flush == FL) {
             since_flush = 0;
 #pragma unroll
@@ -267,10 +270,25 @@ __global__ __launch_bounds__(256) void a16_transpose_kernel(const float *__restr
 // LDS costs 3 more fp16 MFMAs per 16 x 16 x 32 (as cheap as the cross product's own) and the two sums ride along.
 //   * W rows of the block: kq-contiguous split copy W16c [npad][2][64], held in registers (A operand, M = i, K = kq);
 //   * H columns of the stage: kq-contiguous split copy H16c [mpad][2][64], a third LDS image (B operand, N = j);
-//   * a(i, j) is rebuilt from the hi/lo halves already in the A image (hi + lo * 2^-11: 22 bits);
+//   * a(i, j) is rebuilt from the hi/lo halves already in the A image (hi + lo * 2^-11: 22 bits), moved into the accumulator
+//     layout of W H by one-hot MFMAs on the fragment (exact: one product with 1.0 per element);
 //   * the two sums: fp32 over the 16 elements of a lane per stage, fp64 across stages, one pair per block in `partial`.
-// Ring of 2 stages (3 images of 32 + 16 + 16 KB each).  No missing values, no masks on A (host falls back to errors_f32_kernel).
-#define XPROD16_ERR_BUF (XPROD_A_IMG_BYTES + 64 * XPROD_ROWB + 64 * XPROD_ROWB)
+// No missing values, no masks on A (host falls back to errors_f32_kernel).
+//
+// Wavefront-specialised (round 5): a wavefront owns 32 rows of the block and ONE of the two jobs.
+//   * wavefronts 0..3 ("E", rows 32 rg ..): W H and the error arithmetic.  W fragments of two M-tiles stay in registers, every H
+//     fragment is read once per 32 rows, and the arithmetic of column tile t runs in the shadow of the MFMAs of tile t + 1;
+//   * wavefronts 4..7 ("X", same rows): the cross product (every Y fragment read once per 32 rows) and ALL of the block's requests.
+//     A wavefront that hands 16 KB of requests to the memory pipeline sits in the issue queue until most of the previous stage has
+//     been delivered (~1100 cycles at config 2); while it does, the E wavefront of its SIMD has the matrix and vector pipes.
+// The rounds 1-4 form (eight wavefronts x 16 rows, each doing both jobs and its share of the requests: scripts/exp/k_xerr.h xerr0) spent
+// 2700 of its 5800 cycles per stage with all eight wavefronts in that queue and read 352 KB of fragments per stage; this one reads 192 KB
+// and takes 4000 (0.293 -> 0.228 ms alone at config 2, scripts/exp/xerr_exp.hip).  Row tile 2 rg + mt of this kernel = wavefront 2 rg + mt
+// of the old one, with the same accumulation orders: the cross product is bit-identical to it, the error sums agree to 3e-11 relative
+// (where the compiler contracts the fp32 partial sums of a stage into fmas differs between the two code shapes).
+// LDS: ring of THREE A images (the HBM stream: two stages in flight, counted wait) + two pairs of factor images (L2 hits: one stage in
+// flight) = 96 + 2 x (4 NKQ + 16) KB = 160 KB at NKQ = 4; the block's reduction scratch aliases the ring.
+__host__ __device__ static inline int xprod16_err_lds_bytes(int NKQ) { return 3 * XPROD_A_IMG_BYTES + 2 * (16 * NKQ + 64) * XPROD_ROWB; }
 template <int NKQ>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32_t *__restrict__ A16, int lda, const uint32_t *__restrict__ Y16, int ldy,
                                                                     const uint32_t *__restrict__ H16c, const uint32_t *__restrict__ W16c,
@@ -279,169 +297,233 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                                                                     const int *__restrict__ w_exp, int n_rows, int n_cols,
                                                                     double *__restrict__ partial)
 {
-    constexpr int KP = 16 * NKQ;
     constexpr int FL = XPROD_FLUSH_ELEMS / 64;
-    constexpr int YOFF = XPROD_A_IMG_BYTES, HOFF = XPROD_A_IMG_BYTES + 64 * XPROD_ROWB;
+    constexpr int NC2 = NKQ > 2 ? 2 : 1;                                   // 32-wide chunks of kq that can be non-zero
+    constexpr int HOFF = 16 * NKQ * XPROD_ROWB, FBUF = HOFF + 64 * XPROD_ROWB; // a pair of factor images: [Y: 16 NKQ rows | H: 64 columns]
+    constexpr int FOFF = 3 * XPROD_A_IMG_BYTES;
+    constexpr int A_REQ = XPROD_A_IMG_BYTES / 1024 / 4;                    // requests per X wavefront and A image
+    static_assert(A_REQ == 8, "wait_vmcnt(8) below");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double red[2][XPROD_WAVES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
+    const int rg = wave & 3; // rows 32 rg .. 32 rg + 31 of the block
     const int i0 = blockIdx.x * XPROD_TN_BJ;
     int st0 = stage_begin + blockIdx.y * stages_per_split;
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
+    double *red = (double *)smem; // [2][XPROD_WAVES], after the last fragment read
+    // byte offsets of a lane's fragment inside an image row: 16-byte slot (4 c2 + lg) of the hi half, (8 + 4 c2 + lg) of the lo half
+    const int oh0 = ((0 + lg) ^ l15) * 16, oh1 = ((4 + lg) ^ l15) * 16, ol0 = ((8 + lg) ^ l15) * 16, ol1 = ((12 + lg) ^ l15) * 16;
 
-    f32x4 accm[NKQ], accx[NKQ];
-    f64x4 acc64[NKQ];
+    if (wave >= XPROD_WAVES / 2) {
+        // ---------------------------------------------------------------- X: cross product + requests
+        f32x4 accm[2][NKQ], accx[2][NKQ];
+        f64x4 acc64[2][NKQ];
 #pragma unroll
-    for (int b = 0; b < NKQ; b++) {
-        accm[b] = f32x4{0, 0, 0, 0};
-        accx[b] = f32x4{0, 0, 0, 0};
-        acc64[b] = f64x4{0, 0, 0, 0};
-    }
-    // this wave's 16 rows of W, kq-contiguous: lane (l15 = row, lg) holds kq = 32c + 8lg .. +7 of both halves
-    xh8 wh[2], wl[2];
-    {
-        const _Float16 *wrow = (const _Float16 *)(W16c + (size_t)(i0 + 16 * wave + l15) * 64);
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            wh[c] = *(const xh8 *)(wrow + 32 * c + 8 * lg);
-            wl[c] = *(const xh8 *)(wrow + 64 + 32 * c + 8 * lg);
-        }
-    }
-    // one-hot B operands that move the A fragment (M = row, K = 32 columns) into the accumulator layout of W H:
-    // ident[u][k] = 1 iff column k of the K chunk is column 16u + n of the lane's 16-column tile (n = l15)
-    xh8 ident[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) ident[u][e] = (8 * lg + e == 16 * u + l15) ? (_Float16)1.0f : (_Float16)0.0f;
-    const float ca = ldexpf(1.0f, -scal_exp[0]);                    // a      = (hi + lo/2048) * ca
-    const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1]));      // (W H)  = (main + cross/2048) * cwh
-    double s2 = 0.0, skl = 0.0;
-
-    auto issue = [&](int st, unsigned char *buf) {
-        const size_t c0 = (size_t)st * 64;
-#pragma unroll
-        for (int t = wave; t < XPROD_A_IMG_BYTES / 1024; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(A16 + (size_t)(i0 + row) * lda + c0 + s * 4, buf + t * 1024);
-        }
-#pragma unroll
-        for (int t = wave; t < KP / 4; t += XPROD_WAVES) {
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(Y16 + (size_t)row * ldy + c0 + s * 4, buf + YOFF + t * 1024);
-        }
-#pragma unroll
-        for (int t = wave; t < 16; t += XPROD_WAVES) { // 64 columns j of the stage, 256 bytes (64 hi | 64 lo over kq) each
-            const int row = 4 * t + lg;
-            const int s = l15 ^ (row & 15);
-            glds16(H16c + (c0 + row) * 64 + s * 4, buf + HOFF + t * 1024);
-        }
-    };
-    if (st0 < st1) issue(st0, smem);
-    int since_flush = 0;
-    for (int st = st0; st < st1; ++st) {
-        unsigned char *buf = smem + ((st - st0) & 1) * XPROD16_ERR_BUF;
-        wait_vmcnt(0);
-        __builtin_amdgcn_s_barrier();
-        if (st + 1 < st1) issue(st + 1, smem + ((st + 1 - st0) & 1) * XPROD16_ERR_BUF);
-        f32x4 em[4], ex[4], dh[4], dl[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) em[t] = f32x4{0, 0, 0, 0}, ex[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            const int arow = 16 * wave + l15;
-            const int sh = (4 * c2 + lg), sl = 8 + 4 * c2 + lg;
-            const xh8 ah = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sh ^ l15) * 16));
-            const xh8 al = *(const xh8 *)(buf + arow * XPROD_ROWB + ((sl ^ l15) * 16));
-#pragma unroll
-            for (int nt = 0; nt < NKQ; nt++) {
-                const unsigned char *yrow = buf + YOFF + (16 * nt + l15) * XPROD_ROWB;
-                const xh8 yh = *(const xh8 *)(yrow + ((sh ^ l15) * 16));
-                const xh8 yl = *(const xh8 *)(yrow + ((sl ^ l15) * 16));
-                accm[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, accm[nt], 0, 0, 0);
-                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, accx[nt], 0, 0, 0);
-                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, accx[nt], 0, 0, 0);
-            }
-            // a(i, j) of this wave's rows in the accumulator layout (exact: one product with 1.0 per element)
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                dh[2 * c2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ident[u], f32x4{0, 0, 0, 0}, 0, 0, 0);
-                dl[2 * c2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ident[u], f32x4{0, 0, 0, 0}, 0, 0, 0);
-            }
-            // W H for this wave's 16 rows x the stage's 64 columns (contraction over kq = 32*c2 ..)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const unsigned char *hrow = buf + HOFF + (16 * t + l15) * XPROD_ROWB;
-                const xh8 hh = *(const xh8 *)(hrow + ((sh ^ l15) * 16));
-                const xh8 hl = *(const xh8 *)(hrow + ((sl ^ l15) * 16));
-                em[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c2], hh, em[t], 0, 0, 0);
-                ex[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c2], hl, ex[t], 0, 0, 0);
-                ex[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c2], hh, ex[t], 0, 0, 0);
-            }
-        }
-        // the two sums over the 16 x 64 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r (vector arithmetic over
-        // r so that the multiplies and adds pair up into v_pk_*_f32)
-        {
-            f32x4 p2 = f32x4{0, 0, 0, 0}, pk = f32x4{0, 0, 0, 0};
-            const bool interior = (i0 + XPROD_TN_BJ <= n_rows) && (st * 64 + 64 <= n_cols);
-            const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const f32x4 aa = (dh[t] + dl[t] * il) * ca;
-                const f32x4 ah2 = (em[t] + ex[t] * il) * cwh;
-                const f32x4 d = aa - ah2;
-                f32x4 lg4;
-#pragma unroll
-                for (int r = 0; r < 4; r++) lg4[r] = log2_native(ah2[r] + tiny); // (log2: ln 2 goes into the coefficient)
-                f32x4 t2 = d * d;
-                f32x4 tk = ah2 - (aa * NNLM_LN2F + tiny * NNLM_LN2F) * lg4;
-                if (!interior) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool valid = (i0 + 16 * wave + 4 * lg + r < n_rows) && (st * 64 + 16 * t + l15 < n_cols);
-                        if (!valid) t2[r] = 0.f, tk[r] = 0.f;
-                    }
-                }
-                p2 += t2;
-                pk += tk;
-            }
-            s2 += (double)((p2[0] + p2[1]) + (p2[2] + p2[3]));
-            skl += (double)((pk[0] + pk[1]) + (pk[2] + pk[3]));
-        }
-        if (++since_flush == FL) {
-            since_flush = 0;
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
             for (int b = 0; b < NKQ; b++) {
+                accm[mt][b] = f32x4{0, 0, 0, 0};
+                accx[mt][b] = f32x4{0, 0, 0, 0};
+                acc64[mt][b] = f64x4{0, 0, 0, 0};
+            }
+        // piece t = rg + 4 i of an image = rows 4 t + lg = rw + 16 i: (row & 15) = rw & 15 for every i, so one per-lane byte offset
+        // per image serves all of a wavefront's requests (slots XOR-swizzled through the global source address, as in k_xprod.h)
+        const int rw = 4 * rg + lg, sw = l15 ^ (rw & 15);
+        const unsigned voffA = (unsigned)(((size_t)rw * lda + sw * 4) * 4), voffY = (unsigned)(((size_t)rw * ldy + sw * 4) * 4);
+        const unsigned voffH = (unsigned)((rw * 64 + sw * 4) * 4);
+        const unsigned long long baseA = xp_uniform64(A16 + (size_t)i0 * lda), baseY = xp_uniform64(Y16), baseH = xp_uniform64(H16c);
+        const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
+        auto issue_a = [&](int st) {
+            const unsigned long long c0b = (unsigned long long)st * 256ull;
+            const unsigned dst = lds0 + (unsigned)((st - st0) % 3) * (unsigned)XPROD_A_IMG_BYTES + (unsigned)rg * 1024u;
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc64[b][r] += (double)accm[b][r] + (double)accx[b][r] * (1.0 / XPROD16_LO_SCALE);
-                accm[b] = f32x4{0, 0, 0, 0};
-                accx[b] = f32x4{0, 0, 0, 0};
+            for (int i = 0; i < A_REQ; i++) glds16_s(voffA, baseA + c0b + (unsigned long long)i * 16ull * (unsigned long long)lda * 4ull, dst + (unsigned)i * 4096u);
+        };
+        auto issue_f = [&](int st) { // factor rows (Y, 64 columns j of the stage each) and factor columns (H, 64 kq each)
+            const unsigned long long c0b = (unsigned long long)st * 256ull;
+            const unsigned dst = lds0 + (unsigned)FOFF + (unsigned)((st - st0) & 1) * (unsigned)FBUF + (unsigned)rg * 1024u;
+#pragma unroll
+            for (int i = 0; i < NKQ; i++) glds16_s(voffY, baseY + c0b + (unsigned long long)i * 16ull * (unsigned long long)ldy * 4ull, dst + (unsigned)i * 4096u);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                glds16_s(voffH, baseH + (unsigned long long)st * 64ull * 256ull + (unsigned long long)i * 16ull * 256ull, dst + (unsigned)HOFF + (unsigned)i * 4096u);
+        };
+        if (st0 < st1) {
+            issue_f(st0);
+            issue_a(st0);
+        }
+        if (st0 + 1 < st1) issue_a(st0 + 1);
+        int since_flush = 0;
+        for (int st = st0; st < st1; ++st) {
+            const unsigned char *abuf = smem + ((st - st0) % 3) * XPROD_A_IMG_BYTES, *fbuf = smem + FOFF + ((st - st0) & 1) * FBUF;
+            // requests complete in issue order: behind this stage's images only the A image of the next stage has been issued
+            if (st + 1 < st1) wait_vmcnt(A_REQ);
+            else wait_vmcnt(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + 1 < st1) issue_f(st + 1);
+            if (st + 2 < st1) issue_a(st + 2);
+            const unsigned char *arow0 = abuf + (32 * rg + l15) * XPROD_ROWB, *arow1 = arow0 + 16 * XPROD_ROWB;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks of the stage's 64 columns
+                const int oh = c2 ? oh1 : oh0, ol = c2 ? ol1 : ol0;
+                const xh8 ah0 = *(const xh8 *)(arow0 + oh), al0 = *(const xh8 *)(arow0 + ol);
+                const xh8 ah1 = *(const xh8 *)(arow1 + oh), al1 = *(const xh8 *)(arow1 + ol);
+#pragma unroll
+                for (int nt = 0; nt < NKQ; nt++) {
+                    const unsigned char *yrow = fbuf + (16 * nt + l15) * XPROD_ROWB;
+                    const xh8 yh = *(const xh8 *)(yrow + oh);
+                    const xh8 yl = *(const xh8 *)(yrow + ol);
+                    accm[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, yh, accm[0][nt], 0, 0, 0);
+                    accx[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, yl, accx[0][nt], 0, 0, 0);
+                    accx[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, yh, accx[0][nt], 0, 0, 0);
+                    accm[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, yh, accm[1][nt], 0, 0, 0);
+                    accx[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, yl, accx[1][nt], 0, 0, 0);
+                    accx[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, yh, accx[1][nt], 0, 0, 0);
+                }
+            }
+            if (++since_flush == FL) {
+                since_flush = 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int b = 0; b < NKQ; b++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc64[mt][b][r] += (double)accm[mt][b][r] + (double)accx[mt][b][r] * (1.0 / XPROD16_LO_SCALE);
+                        accm[mt][b] = f32x4{0, 0, 0, 0};
+                        accx[mt][b] = f32x4{0, 0, 0, 0};
+                    }
             }
         }
-    }
-    const double unscale = ldexp(1.0, -(scal_exp[0] + scal_exp[1]));
-    double *out = Cx + (size_t)blockIdx.y * slab_stride;
+        const double unscale = ldexp(1.0, -(scal_exp[0] + scal_exp[1]));
+        double *out = Cx + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
-    for (int nt = 0; nt < NKQ; nt++)
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int kq = 16 * nt + l15;
-            const int j = i0 + 16 * wave + 4 * lg + r;
-            const double v = acc64[nt][r] + (double)accm[nt][r] + (double)accx[nt][r] * (1.0 / XPROD16_LO_SCALE);
-            out[(size_t)kq * ldc + j] = v * unscale;
+            for (int nt = 0; nt < NKQ; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kq = 16 * nt + l15;
+                    const int j = i0 + 32 * rg + 16 * mt + 4 * lg + r;
+                    const double v = acc64[mt][nt][r] + (double)accm[mt][nt][r] + (double)accx[mt][nt][r] * (1.0 / XPROD16_LO_SCALE);
+                    out[(size_t)kq * ldc + j] = v * unscale;
+                }
+        __syncthreads(); // (pairs with the E wavefronts' barrier in front of their use of the ring as scratch)
+    } else {
+        // ---------------------------------------------------------------- E: W H and the two error sums
+        // this wavefront's 32 rows of W, kq-contiguous: lane (l15 = row, lg) holds kq = 32c + 8lg .. +7 of both halves
+        xh8 wh[2][NC2], wl[2][NC2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const _Float16 *wrow = (const _Float16 *)(W16c + (size_t)(i0 + 32 * rg + 16 * mt + l15) * 64);
+#pragma unroll
+            for (int c = 0; c < NC2; c++) {
+                wh[mt][c] = *(const xh8 *)(wrow + 32 * c + 8 * lg);
+                wl[mt][c] = *(const xh8 *)(wrow + 64 + 32 * c + 8 * lg);
+            }
         }
-    s2 = wave_sum(s2);
-    skl = wave_sum(skl);
-    if (lane == 0) red[0][wave] = s2, red[1][wave] = skl;
+        // one-hot B operands that move the A fragment (M = row, K = 32 columns) into the accumulator layout of W H:
+        // ident[u][k] = 1 iff column k of the K chunk is column 16u + n of the lane's 16-column tile (n = l15)
+        xh8 ident[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) ident[u][e] = (8 * lg + e == 16 * u + l15) ? (_Float16)1.0f : (_Float16)0.0f;
+        const float ca = ldexpf(1.0f, -scal_exp[0]);               // a      = (hi + lo/2048) * ca
+        const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1])); // (W H)  = (main + cross/2048) * cwh
+        const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
+        double s2[2] = {0.0, 0.0}, skl[2] = {0.0, 0.0}; // per M-tile, as the two 16-row wavefronts of the old form kept them
+        for (int st = st0; st < st1; ++st) {
+            const unsigned char *abuf = smem + ((st - st0) % 3) * XPROD_A_IMG_BYTES, *fbuf = smem + FOFF + ((st - st0) & 1) * FBUF;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool interior = (i0 + XPROD_TN_BJ <= n_rows) && (st * 64 + 64 <= n_cols);
+            // two copies of the stage: the interior one has no edge tests and is a single basic block (MFMAs and arithmetic interleave)
+            auto stage_body = [&](auto interior_c) {
+                constexpr bool INTERIOR = decltype(interior_c)::value;
+                const unsigned char *arow0 = abuf + (32 * rg + l15) * XPROD_ROWB, *arow1 = arow0 + 16 * XPROD_ROWB;
+                xh8 ah[2][2], al[2][2]; // [M-tile][K chunk of the stage's columns]
+                ah[0][0] = *(const xh8 *)(arow0 + oh0), al[0][0] = *(const xh8 *)(arow0 + ol0);
+                ah[1][0] = *(const xh8 *)(arow1 + oh0), al[1][0] = *(const xh8 *)(arow1 + ol0);
+                ah[0][1] = *(const xh8 *)(arow0 + oh1), al[0][1] = *(const xh8 *)(arow0 + ol1);
+                ah[1][1] = *(const xh8 *)(arow1 + oh1), al[1][1] = *(const xh8 *)(arow1 + ol1);
+                xh8 hh[2][NC2], hl[2][NC2]; // [buffer][K chunk of kq]: H fragments of column tile t and t + 1
+                auto read_h = [&](int t, int b) {
+                    const unsigned char *hrow = fbuf + HOFF + (16 * t + l15) * XPROD_ROWB;
+                    hh[b][0] = *(const xh8 *)(hrow + oh0), hl[b][0] = *(const xh8 *)(hrow + ol0);
+                    if constexpr (NC2 > 1) hh[b][NC2 - 1] = *(const xh8 *)(hrow + oh1), hl[b][NC2 - 1] = *(const xh8 *)(hrow + ol1);
+                };
+                read_h(0, 0);
+                f32x4 em[2][2], ex[2][2], dh[2][2], dl[2][2]; // [buffer][M-tile]: W H (main, cross) and a (hi, lo) of a 16 x 16 tile
+                f32x4 p2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, pk[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                // the two sums over a 16 x 16 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r (vector arithmetic over r)
+                auto sums = [&](int t, int b) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++) {
+                        const f32x4 aa = (dh[b][mt] + dl[b][mt] * il) * ca;
+                        const f32x4 ah2 = (em[b][mt] + ex[b][mt] * il) * cwh;
+                        const f32x4 d = aa - ah2;
+                        f32x4 lg4;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) lg4[r] = log2_native(ah2[r] + tiny); // (log2: ln 2 goes into the coefficient)
+                        f32x4 t2 = d * d;
+                        f32x4 tk = ah2 - (aa * NNLM_LN2F + tiny * NNLM_LN2F) * lg4;
+                        if constexpr (!INTERIOR) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const bool valid = (i0 + 32 * rg + 16 * mt + 4 * lg + r < n_rows) && (st * 64 + 16 * t + l15 < n_cols);
+                                if (!valid) t2[r] = 0.f, tk[r] = 0.f;
+                            }
+                        }
+                        p2[mt] += t2;
+                        pk[mt] += tk;
+                    }
+                };
+#pragma unroll
+                for (int t = 0; t < 4; t++) { // column tile t of the stage; its columns are K chunk t / 2, half t % 2 of the A fragment
+                    const int b = t & 1;
+                    if (t < 3) read_h(t + 1, b ^ 1);
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++) {
+                        dh[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                        dl[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++) {
+                        em[b][mt] = f32x4{0, 0, 0, 0}, ex[b][mt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                        for (int c2 = 0; c2 < NC2; c2++) {
+                            em[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt][c2], hh[b][c2], em[b][mt], 0, 0, 0);
+                            ex[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt][c2], hl[b][c2], ex[b][mt], 0, 0, 0);
+                            ex[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt][c2], hh[b][c2], ex[b][mt], 0, 0, 0);
+                        }
+                    }
+                    if (t > 0) sums(t - 1, b ^ 1); // (in the shadow of the MFMAs just issued)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                sums(3, 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) {
+                    s2[mt] += (double)((p2[mt][0] + p2[mt][1]) + (p2[mt][2] + p2[mt][3]));
+                    skl[mt] += (double)((pk[mt][0] + pk[mt][1]) + (pk[mt][2] + pk[mt][3]));
+                }
+            };
+            if (interior) stage_body(std::true_type{});
+            else stage_body(std::false_type{});
+        }
+        __syncthreads(); // every fragment read of the block is done: the ring becomes the reduction scratch
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const double a = wave_sum(s2[mt]), b = wave_sum(skl[mt]);
+            if (lane == 0) red[2 * rg + mt] = a, red[XPROD_WAVES + 2 * rg + mt] = b;
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         double a2 = 0.0, ak = 0.0;
-        for (int w = 0; w < XPROD_WAVES; w++) a2 += red[0][w], ak += red[1][w];
+        for (int w = 0; w < XPROD_WAVES; w++) a2 += red[w], ak += red[XPROD_WAVES + w]; // (row tiles in the old form's wavefront order)
         const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         partial[2 * blk] = a2;
         partial[2 * blk + 1] = ak;

@@ -942,7 +942,7 @@ template <int NKQ>
 static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
 {
     dim3 grid(p.tiles_x, p.S);
-    const int lds = 2 * XPROD16_ERR_BUF;
+    const int lds = xprod16_err_lds_bytes(NKQ);
     set_dyn_lds((const void *)xprod16_err_kernel<NKQ>, lds, "xprod16_err_kernel");
     xprod16_err_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
                                                                      (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,

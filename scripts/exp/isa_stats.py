@@ -13,6 +13,8 @@ if len(sys.argv) > 3:
     j = s.index('.Lfunc_end', i)
     def cls(op):
         if op.startswith('v_rcp_f32'): return 'RCP'
+        if op.startswith('v_mfma'): return 'MFMA'
+        if op.startswith('v_log') or op.startswith('v_exp'): return 'LOG'
         if op.startswith('v_pk_'): return 'PK'
         if op.startswith('ds_read'): return 'DSR'
         if op.startswith('ds_write'): return 'DSW'
