@@ -79,7 +79,8 @@ __device__ static inline int strided_count(int wave, int cnt) { return (wave < c
 // Wave w owns image rows (columns j) [16w, 16w+16): one M-tile x NKQ N-tiles.
 // ------------------------------------------------------------------------------------------------
 // EXP: ablation switches for scripts/exp/xprod_exp.hip only (0 in the product): bit0 load the factor image only for the
-// first two stages, bit1 skip the MFMA phase, bit2 load the A image only for the first two stages.
+// first two stages, bit1 skip the MFMA phase, bit2 load the A image only for the first two stages, bit5 every wavefront issues its requests in
+// front of its MFMA phase (the form before round 5).
 typedef float xp_f32x2 __attribute__((ext_vector_type(2)));
 typedef double xp_f64x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct XpVec2;
@@ -156,6 +157,13 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     if (EXP & 1) per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES;
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
+    // fp64 (round 5): wavefronts 4..7 hand their requests of stage st + 2 to the memory pipeline BEHIND their MFMA phase, wavefronts 0..3
+    // in front of it.  A wavefront sits in the issue queue until the pipeline takes its 5-6 KB (most of a stage's HBM time when all eight
+    // ask at once) and issues no MFMA meanwhile; with the two wavefronts of a SIMD asking at different times one of them computes --
+    // 0.392 -> 0.377 ms (H) / 0.399 -> 0.385 (W) at config 2 (scripts/exp/xprod64_exp.hip).  The split-fp16 kernel's MFMA phase is a
+    // quarter of this one's and gains nothing (k_xprod16.h, EXP bit 3).  Same buffers, same counted waits: requests complete in issue
+    // order per wavefront, and stage st + 2's buffer is free from the barrier of stage st on.
+    const bool late = sizeof(T) == 8 && !(EXP & (32 | 16)) && wave >= XPROD_WAVES / 2;
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
         unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
             wait_vmcnt((st + 1 < st1) ? per_stage : 0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+            if (st + 2 < st1 && !late) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
         }
         if (EXP & 2) continue;
 #pragma unroll
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
                         tacc[u] = __builtin_elementwise_fma(v2_t{a[e], a[e + 1]}, v2_t{w[u][e], w[u][e + 1]}, tacc[u]);
             }
         }
+        if (late && st + 2 < st1) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
         if constexpr (sizeof(T) == 4) {
             if (++since_flush == FL) {
                 since_flush = 0;
