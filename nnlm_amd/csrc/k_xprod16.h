@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void a16_transpose_kernel(const float *__restr
 //   * W rows of the block: kq-contiguous split copy W16c [npad][2][64], held in registers (A operand, M = i, K = kq);
 //   * H columns of the stage: kq-contiguous split copy H16c [mpad][2][64], a third LDS image (B operand, N = j);
 //   * a(i, j) is rebuilt from the hi/lo halves already in the A image (hi + lo * 2^-11: 22 bits), moved into the accumulator
-//     layout of W H by one-hot MFMAs on the fragment (exact: one product with 1.0 per element);
+//     layout of W H by a one-hot MFMA (exact: one product with 1.0 and one with 2^-11 per element);
 //   * the two sums: fp32 over the 16 elements of a lane per stage, fp64 across stages, one pair per block in `partial`.
 // No missing values, no masks on A (host falls back to errors_f32_kernel).
 //
@@ -424,13 +424,15 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                 wl[mt][c] = *(const xh8 *)(wrow + 64 + 32 * c + 8 * lg);
             }
         }
-        // one-hot B operands that move the A fragment (M = row, K = 32 columns) into the accumulator layout of W H:
-        // ident[u][k] = 1 iff column k of the K chunk is column 16u + n of the lane's 16-column tile (n = l15)
-        xh8 ident[2];
+        // a(i, j) of a 16 x 16 tile in the accumulator layout of W H by ONE MFMA: its A operand holds the hi halves of the tile's 16 columns
+        // in K slots 0..15 and their lo halves in slots 16..31 (lane group lg reads slot 2 t + lg of the hi half of the image row for
+        // lg < 2, slot 2 t + lg - 2 of the lo half otherwise), the B operand is 1 at slot n and 2^-11 at slot 16 + n for the lane's column
+        // n = l15: D = hi + lo * 2^-11, exact in fp32 (22 bits).
+        xh8 identm;
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) ident[u][e] = (8 * lg + e == 16 * u + l15) ? (_Float16)1.0f : (_Float16)0.0f;
+        for (int e = 0; e < 8; e++)
+            identm[e] = (8 * lg + e == l15) ? (_Float16)1.0f : (8 * lg + e == 16 + l15) ? (_Float16)(1.0f / XPROD16_LO_SCALE) : (_Float16)0.0f;
+        const int amslot = (lg < 2 ? 0 : 8) + (lg & 1);
         const float ca = ldexpf(1.0f, -scal_exp[0]);               // a      = (hi + lo/2048) * ca
         const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1])); // (W H)  = (main + cross/2048) * cwh
         const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
@@ -444,11 +446,12 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
             auto stage_body = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
                 const unsigned char *arow0 = abuf + (32 * rg + l15) * XPROD_ROWB, *arow1 = arow0 + 16 * XPROD_ROWB;
-                xh8 ah[2][2], al[2][2]; // [M-tile][K chunk of the stage's columns]
-                ah[0][0] = *(const xh8 *)(arow0 + oh0), al[0][0] = *(const xh8 *)(arow0 + ol0);
-                ah[1][0] = *(const xh8 *)(arow1 + oh0), al[1][0] = *(const xh8 *)(arow1 + ol0);
-                ah[0][1] = *(const xh8 *)(arow0 + oh1), al[0][1] = *(const xh8 *)(arow0 + ol1);
-                ah[1][1] = *(const xh8 *)(arow1 + oh1), al[1][1] = *(const xh8 *)(arow1 + ol1);
+                xh8 am[2][4]; // [M-tile][column tile]: hi | lo halves of a(i, 16 t .. 16 t + 15)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    am[0][t] = *(const xh8 *)(arow0 + (((amslot + 2 * t) ^ l15) * 16));
+                    am[1][t] = *(const xh8 *)(arow1 + (((amslot + 2 * t) ^ l15) * 16));
+                }
                 xh8 hh[2][NC2], hl[2][NC2]; // [buffer][K chunk of kq]: H fragments of column tile t and t + 1
                 auto read_h = [&](int t, int b) {
                     const unsigned char *hrow = fbuf + HOFF + (16 * t + l15) * XPROD_ROWB;
@@ -456,13 +459,13 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                     if constexpr (NC2 > 1) hh[b][NC2 - 1] = *(const xh8 *)(hrow + oh1), hl[b][NC2 - 1] = *(const xh8 *)(hrow + ol1);
                 };
                 read_h(0, 0);
-                f32x4 em[2][2], ex[2][2], dh[2][2], dl[2][2]; // [buffer][M-tile]: W H (main, cross) and a (hi, lo) of a 16 x 16 tile
+                f32x4 em[2][2], ex[2][2], da[2][2]; // [buffer][M-tile]: W H (main, cross) and a of a 16 x 16 tile, all still scaled
                 f32x4 p2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, pk[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
                 // the two sums over a 16 x 16 tile: lane (l15 = column within tile t, lg) holds rows 4*lg + r (vector arithmetic over r)
                 auto sums = [&](int t, int b) {
 #pragma unroll
                     for (int mt = 0; mt < 2; mt++) {
-                        const f32x4 aa = (dh[b][mt] + dl[b][mt] * il) * ca;
+                        const f32x4 aa = da[b][mt] * ca;
                         const f32x4 ah2 = (em[b][mt] + ex[b][mt] * il) * cwh;
                         const f32x4 d = aa - ah2;
                         f32x4 lg4;
@@ -482,14 +485,11 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                     }
                 };
 #pragma unroll
-                for (int t = 0; t < 4; t++) { // column tile t of the stage; its columns are K chunk t / 2, half t % 2 of the A fragment
+                for (int t = 0; t < 4; t++) { // column tile t of the stage
                     const int b = t & 1;
                     if (t < 3) read_h(t + 1, b ^ 1);
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) {
-                        dh[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
-                        dl[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
-                    }
+                    for (int mt = 0; mt < 2; mt++) da[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[mt][t], identm, f32x4{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < 2; mt++) {
                         em[b][mt] = f32x4{0, 0, 0, 0}, ex[b][mt] = f32x4{0, 0, 0, 0};

@@ -1395,6 +1395,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xerr7_kernel(const uint32_t *__
         for (int u = 0; u < 2; u++)
 #pragma unroll
             for (int e = 0; e < 8; e++) ident[u][e] = (8 * lg + e == 16 * u + l15) ? (_Float16)1.0f : (_Float16)0.0f;
+        xh8 identm; // K slot 8 lg + e: 1 at slot n (hi half of column n of the tile), 2^-11 at slot 16 + n (its lo half), n = l15
+#pragma unroll
+        for (int e = 0; e < 8; e++) identm[e] = (8 * lg + e == l15) ? (_Float16)1.0f : (8 * lg + e == 16 + l15) ? (_Float16)(1.0f / XPROD16_LO_SCALE) : (_Float16)0.0f;
         const float ca = ldexpf(1.0f, -scal_exp[0]);
         const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1]));
         const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
@@ -1410,10 +1413,20 @@ __global__ __launch_bounds__(XPROD_THREADS) void xerr7_kernel(const uint32_t *__
             constexpr bool INTERIOR = decltype(interior_c)::value;
             const unsigned char *arow0 = abuf + (32 * rg + l15) * XPROD_ROWB, *arow1 = arow0 + 16 * XPROD_ROWB;
             xh8 ah[2][2], al[2][2]; // [M-tile][K chunk]
+            xh8 am[2][4];           // (ABL 32) [M-tile][column tile]: K slots 0..15 = hi halves of the tile's 16 columns, 16..31 = their lo halves
+            if (ABL & 32) {
+                const int bs = (lg < 2 ? 0 : 8) + (lg & 1);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    am[0][t] = *(const xh8 *)(arow0 + (((bs + 2 * t) ^ l15) * 16));
+                    am[1][t] = *(const xh8 *)(arow1 + (((bs + 2 * t) ^ l15) * 16));
+                }
+            } else {
             ah[0][0] = *(const xh8 *)(arow0 + oh0), al[0][0] = *(const xh8 *)(arow0 + ol0);
             ah[1][0] = *(const xh8 *)(arow1 + oh0), al[1][0] = *(const xh8 *)(arow1 + ol0);
             ah[0][1] = *(const xh8 *)(arow0 + oh1), al[0][1] = *(const xh8 *)(arow0 + ol1);
             ah[1][1] = *(const xh8 *)(arow1 + oh1), al[1][1] = *(const xh8 *)(arow1 + ol1);
+            }
             xh8 hh[2][2], hl[2][2]; // [buffer][K chunk]
             auto read_h = [&](int t, int b) {
                 const unsigned char *hrow = fbuf + HOFF + (16 * t + l15) * XPROD_ROWB;
@@ -1426,7 +1439,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xerr7_kernel(const uint32_t *__
             auto epi = [&](int t, int b) {
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++) {
-                    const f32x4 aa = (dh[b][mt] + dl[b][mt] * il) * ca;
+                    const f32x4 aa = (ABL & 32) ? dh[b][mt] * ca : (dh[b][mt] + dl[b][mt] * il) * ca;
                     const f32x4 ah2 = (em[b][mt] + ex[b][mt] * il) * cwh;
                     const f32x4 d = aa - ah2;
                     f32x4 lg4;
@@ -1451,8 +1464,11 @@ __global__ __launch_bounds__(XPROD_THREADS) void xerr7_kernel(const uint32_t *__
                 if (t < 3) read_h(t + 1, b ^ 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++) {
+                    if (ABL & 32) dh[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[mt][t], identm, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    else {
                     dh[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
                     dl[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][t >> 1], ident[t & 1], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    }
                 }
                 if (ABL & 8) { // the two M-tiles alternate: no MFMA directly behind one on the same accumulator
 #pragma unroll
@@ -1572,6 +1588,8 @@ static int xerr_launch(int v, dim3 grid, const uint32_t *A16T, int mpad, const u
     case 23: return xerr7_launch<8, 0>(grid, A16T, mpad, Y16, H16c, W16c, C, npad, slab, stages, sps, scal, n, m, P, tim);
     case 24: return xerr7_launch<16, 0>(grid, A16T, mpad, Y16, H16c, W16c, C, npad, slab, stages, sps, scal, n, m, P, tim);
     case 25: return xerr7_launch<24, 0>(grid, A16T, mpad, Y16, H16c, W16c, C, npad, slab, stages, sps, scal, n, m, P, tim);
+    case 26: return xerr7_launch<32, 0>(grid, A16T, mpad, Y16, H16c, W16c, C, npad, slab, stages, sps, scal, n, m, P, tim);
+    case 36: return xerr7_launch<32, 1>(grid, A16T, mpad, Y16, H16c, W16c, C, npad, slab, stages, sps, scal, n, m, P, tim);
     default: return 1;
     }
 }

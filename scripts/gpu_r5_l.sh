@@ -3,7 +3,7 @@
 # form, parity tests that go through it, bench lines
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r05
-bash scripts/exp/xerr_run.sh l "0 50 0 50 0 50" > /dev/null 2>&1
+bash scripts/exp/xerr_run.sh l "0 26 50 0 26 50" > /dev/null 2>&1
 F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_edges.py -x -q -m gpu 2>&1 | grep -v "$F" | tail -5 > gpurun_out/r05/l_tests.log
 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_boundary.py -x -q -m gpu 2>&1 | grep -v "$F" | tail -5 >> gpurun_out/r05/l_tests.log
