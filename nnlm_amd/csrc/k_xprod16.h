@@ -295,7 +295,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                                                                     double *__restrict__ Cx, int ldc, size_t slab_stride, int stage_begin,
                                                                     int stage_end, int stages_per_split, const int *__restrict__ scal_exp,
                                                                     const int *__restrict__ w_exp, int n_rows, int n_cols,
-                                                                    double *__restrict__ partial)
+                                                                    double *__restrict__ partial, unsigned *__restrict__ zero_word)
 {
     constexpr int FL = XPROD_FLUSH_ELEMS / 64;
     constexpr int NC2 = NKQ > 2 ? 2 : 1;                                   // 32-wide chunks of kq that can be non-zero
@@ -313,6 +313,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
     double *red = (double *)smem; // [2][XPROD_WAVES], after the last fragment read
+    // (the word this half-step's sweep accumulates max|x| into: factor16_fold_err_kernel has read max|W| from it and could not clear it)
+    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *zero_word = 0u;
     // byte offsets of a lane's fragment inside an image row: 16-byte slot (4 c2 + lg) of the hi half, (8 + 4 c2 + lg) of the lo half
     const int oh0 = ((0 + lg) ^ l15) * 16, oh1 = ((4 + lg) ^ l15) * 16, ol0 = ((8 + lg) ^ l15) * 16, ol1 = ((12 + lg) ^ l15) * 16;
 
@@ -554,3 +556,72 @@ __global__ __launch_bounds__(256) void factor16c_kernel(const double *__restrict
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && exp_out) *exp_out = e;
 }
+
+// factor16c_kernel's tile with 1024 threads (device function: blk = 64-column tile)
+__device__ static inline void factor16c_body(const double *__restrict__ X, int ld, int ncols, int k, float scale, uint32_t *__restrict__ X16c, int blk,
+                                             float (*tile)[65])
+{
+    const int c0 = blk * 64;
+    for (int t = threadIdx.x; t < 64 * 64; t += 1024) {
+        const int q = t >> 6, c = t & 63;
+        tile[q][c] = (q < k && c0 + c < ncols) ? (float)X[(size_t)q * ld + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * 64; t += 1024) {
+        const int c = t >> 6, q = t & 63;
+        _Float16 hi, lo;
+        split16(tile[q][c], scale, hi, lo);
+        _Float16 *row = (_Float16 *)(X16c + (size_t)(c0 + c) * 64);
+        row[q] = hi;
+        row[64 + q] = lo;
+    }
+}
+
+// Everything between a sweep and the fused cross product / error block of a trace iteration in ONE launch of 1024-thread blocks
+// (prepare_factor16's three kernels + gram_fold_kernel were 4 launches of 5-9 us each, none of which depends on another):
+//   blocks [0, nfold)            fold the sweep's Gram slabs (+ the operand image of this half-step's sweep)
+//   blocks [nfold, +nf16)        Y16: split rows of the fixed factor H, 1024 entries each                 (exponent -> exp_out[0])
+//   blocks [.., +mpad/64)        H16c: kq-contiguous split copy of H, same exponent
+//   blocks [.., +npad/64)        W16c: kq-contiguous split copy of W, scaled by max|W| that W's sweep left in *wmax (exponent -> w_exp_out)
+// *wmax is the word this half-step's sweep accumulates into: it is cleared by xprod16_err_kernel, which runs between the two.
+__global__ __launch_bounds__(1024) void factor16_fold_err_kernel(const double *__restrict__ Hm, int ldh, int m, const double *__restrict__ Wm, int ldw, int n, int k,
+                                                                 int KP, const unsigned *__restrict__ hmax, const unsigned *__restrict__ wmax,
+                                                                 int *__restrict__ exp_out, int *__restrict__ w_exp_out, uint32_t *__restrict__ Y16,
+                                                                 uint32_t *__restrict__ H16c, uint32_t *__restrict__ W16c, const double *__restrict__ slabs,
+                                                                 int nslabs, double *__restrict__ G, const SweepImg im)
+{
+    __shared__ float tile[64][65];
+    const int nfold = KP * KP / 64, nf16 = (int)(((size_t)KP * ldh + 1023) / 1024), nhc = ldh / 64;
+    int b = blockIdx.x;
+    if (b < nfold) {
+        gram_fold_body(slabs, nslabs, KP, G, b, im);
+        return;
+    }
+    b -= nfold;
+    const int eh = split16_exponent(__uint_as_float(*hmax));
+    if (b < nf16) {
+        const float scale = ldexpf(1.0f, eh);
+        const size_t idx = (size_t)b * 1024 + threadIdx.x; // over KP * ldh
+        if (idx < (size_t)KP * ldh) {
+            const int q = (int)(idx / ldh), i = (int)(idx % ldh);
+            const float v = (q < k && i < m) ? (float)Hm[(size_t)q * ldh + i] : 0.0f;
+            _Float16 hi, lo;
+            split16(v, scale, hi, lo);
+            _Float16 *row = (_Float16 *)(Y16 + (size_t)q * ldh + (size_t)(i >> 6) * 64);
+            row[i & 63] = hi;
+            row[64 + (i & 63)] = lo;
+        }
+        if (idx == 0) *exp_out = eh;
+        return;
+    }
+    b -= nf16;
+    if (b < nhc) {
+        factor16c_body(Hm, ldh, m, k, ldexpf(1.0f, eh), H16c, b, tile);
+        return;
+    }
+    b -= nhc;
+    const int ew = split16_exponent(__uint_as_float(*wmax));
+    factor16c_body(Wm, ldw, n, k, ldexpf(1.0f, ew), W16c, b, tile);
+    if (b == 0 && threadIdx.x == 0) *w_exp_out = ew;
+}
+

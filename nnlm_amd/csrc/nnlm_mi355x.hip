@@ -139,6 +139,7 @@ struct nnlm_handle {
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
     bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
     int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
+    unsigned *err_zero_word = nullptr; // the fused kernel clears this word (max|x| of the sweep that follows it; see factor16_fold_err_kernel)
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
     // profiling
@@ -946,7 +947,8 @@ static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
     set_dyn_lds((const void *)xprod16_err_kernel<NKQ>, lds, "xprod16_err_kernel");
     xprod16_err_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
                                                                      (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
-                                                                     h->scal_exp + 2, h->n, h->m, h->partials);
+                                                                     h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word);
+    h->err_zero_word = nullptr;
     h->fused_nb = p.tiles_x * p.S;
 }
 static void launch_xprod16(nnlm_handle *h, int which, const HalfPlan &p)
@@ -1830,7 +1832,17 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
                 // (the fold of the Gram partial sums also writes the operand image of this half-step's sweep: no sweepq_pack_kernel launch)
                 SweepImg im;
                 im.img = h->sweepq_img, im.NB = (h->k + 3) / 4, im.NP = sweepq_np(im.NB, false), im.k = h->k, im.r0 = reg[0], im.r1 = reg[1];
-                if (h->fuse_err) { // (the fused error block needs more split copies: the general routine)
+                if (h->fuse_err && which == 0 && sg_other == 0) {
+                    // trace iteration, max|W| still in the word W's sweep left it in: the split copies of H (rows and kq-contiguous) and of
+                    // W (kq-contiguous) and the fold in one launch; the fused kernel clears that word for this half-step's sweep
+                    const size_t cnt = (size_t)h->KP * h->mpad;
+                    const unsigned nblk = (unsigned)(h->KP * h->KP / 64 + (cnt + 1023) / 1024 + h->mpad / 64 + h->npad / 64);
+                    factor16_fold_err_kernel<<<nblk, 1024, 0, h->stream>>>(h->H64, h->mpad, h->m, h->W64, h->npad, h->n, h->k, h->KP, h->maxbits + 4 + h->sg_par,
+                                                                           smax_w, h->scal_exp + 1, h->scal_exp + 2, h->Y16, h->H16c, h->W16c, h->sg_slabs,
+                                                                           h->sg_nslabs, h->Graw, im);
+                    h->y16_for = -1;
+                    h->err_zero_word = smax_w;
+                } else if (h->fuse_err) { // (the general routine)
                     prepare_factor16(h, which, h->maxbits + 4 + h->sg_par, smax_w, which == 0 && sg_other == 0);
                     gram_fold_kernel<<<h->KP * h->KP / 64, 1024, 0, h->stream>>>(h->sg_slabs, h->sg_nslabs, h->KP, h->Graw, im);
                 } else {

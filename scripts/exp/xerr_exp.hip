@@ -73,7 +73,7 @@ int main(int argc, char **argv)
         } else if (v == 50) { // the product's kernel
             const int lds = xprod16_err_lds_bytes(4);
             CK(hipFuncSetAttribute((const void *)xprod16_err_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            xprod16_err_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, H16c, W16c, C, npad, slab, 0, stages, sps, scal, scal + 2, n, m, P);
+            xprod16_err_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, H16c, W16c, C, npad, slab, 0, stages, sps, scal, scal + 2, n, m, P, nullptr);
         } else if (v == 1) {
             const int lds = xprod_tn_lds_bytes(KP);
             CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
