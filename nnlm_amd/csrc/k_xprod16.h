@@ -289,13 +289,17 @@ __global__ __launch_bounds__(256) void a16_transpose_kernel(const float *__restr
 // LDS: ring of THREE A images (the HBM stream: two stages in flight, counted wait) + two pairs of factor images (L2 hits: one stage in
 // flight) = 96 + 2 x (4 NKQ + 16) KB = 160 KB at NKQ = 4; the block's reduction scratch aliases the ring.
 __host__ __device__ static inline int xprod16_err_lds_bytes(int NKQ) { return 3 * XPROD_A_IMG_BYTES + 2 * (16 * NKQ + 64) * XPROD_ROWB; }
-template <int NKQ>
+// HAS_MISS: entries of A that are missing (stored as 0 in the split copy, so the cross product is already right) are left out of the two
+// sums -- bit j % 32 of missT[i][j / 32], the transposed bit matrix the W half-step of the NA flow uses; an E wavefront fetches the two
+// words of each of its 32 rows per stage (8 eight-byte loads per lane, 4 distinct addresses per request).
+template <int NKQ, bool HAS_MISS = false>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32_t *__restrict__ A16, int lda, const uint32_t *__restrict__ Y16, int ldy,
                                                                     const uint32_t *__restrict__ H16c, const uint32_t *__restrict__ W16c,
                                                                     double *__restrict__ Cx, int ldc, size_t slab_stride, int stage_begin,
                                                                     int stage_end, int stages_per_split, const int *__restrict__ scal_exp,
                                                                     const int *__restrict__ w_exp, int n_rows, int n_cols,
-                                                                    double *__restrict__ partial, unsigned *__restrict__ zero_word)
+                                                                    double *__restrict__ partial, unsigned *__restrict__ zero_word,
+                                                                    const uint32_t *__restrict__ missT = nullptr, int wordsT = 0)
 {
     constexpr int FL = XPROD_FLUSH_ELEMS / 64;
     constexpr int NC2 = NKQ > 2 ? 2 : 1;                                   // 32-wide chunks of kq that can be non-zero
@@ -439,6 +443,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
         const float cwh = ldexpf(1.0f, -(w_exp[0] + scal_exp[1])); // (W H)  = (main + cross/2048) * cwh
         const float il = 1.0f / XPROD16_LO_SCALE, tiny = (float)NNLM_TINY;
         double s2[2] = {0.0, 0.0}, skl[2] = {0.0, 0.0}; // per M-tile, as the two 16-row wavefronts of the old form kept them
+        const unsigned lanebit[2] = {1u << l15, 1u << (16 + l15)}; // column 16 t + l15 of the stage = bit 16 (t & 1) + l15 of word t / 2
+        const uint32_t *mrow = HAS_MISS ? missT + (size_t)(i0 + 32 * rg + 4 * lg) * wordsT : nullptr;
         for (int st = st0; st < st1; ++st) {
             const unsigned char *abuf = smem + ((st - st0) % 3) * XPROD_A_IMG_BYTES, *fbuf = smem + FOFF + ((st - st0) & 1) * FBUF;
             __builtin_amdgcn_s_barrier();
@@ -448,12 +454,19 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
             auto stage_body = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
                 const unsigned char *arow0 = abuf + (32 * rg + l15) * XPROD_ROWB, *arow1 = arow0 + 16 * XPROD_ROWB;
-                xh8 am[2][4]; // [M-tile][column tile]: hi | lo halves of a(i, 16 t .. 16 t + 15)
+                uint2 mw[2][4]; // [M-tile][r]: the stage's 64 mask bits of row 32 rg + 16 mt + 4 lg + r
+                if constexpr (HAS_MISS) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    am[0][t] = *(const xh8 *)(arow0 + (((amslot + 2 * t) ^ l15) * 16));
-                    am[1][t] = *(const xh8 *)(arow1 + (((amslot + 2 * t) ^ l15) * 16));
+                    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) mw[mt][r] = *(const uint2 *)(mrow + (size_t)(16 * mt + r) * wordsT + 2 * st);
                 }
+                xh8 am[2][2]; // [buffer][M-tile]: hi | lo halves of a(i, 16 t .. 16 t + 15), column tiles t and t + 1
+                auto read_a = [&](int t, int b) {
+                    am[b][0] = *(const xh8 *)(arow0 + (((amslot + 2 * t) ^ l15) * 16));
+                    am[b][1] = *(const xh8 *)(arow1 + (((amslot + 2 * t) ^ l15) * 16));
+                };
+                read_a(0, 0);
                 xh8 hh[2][NC2], hl[2][NC2]; // [buffer][K chunk of kq]: H fragments of column tile t and t + 1
                 auto read_h = [&](int t, int b) {
                     const unsigned char *hrow = fbuf + HOFF + (16 * t + l15) * XPROD_ROWB;
@@ -475,11 +488,17 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                         for (int r = 0; r < 4; r++) lg4[r] = log2_native(ah2[r] + tiny); // (log2: ln 2 goes into the coefficient)
                         f32x4 t2 = d * d;
                         f32x4 tk = ah2 - (aa * NNLM_LN2F + tiny * NNLM_LN2F) * lg4;
-                        if constexpr (!INTERIOR) {
+                        if constexpr (!INTERIOR || HAS_MISS) {
+                            // (selects, no short-circuit: written as `if (!(inside && !missing)) t2 = tk = 0` hipcc 7.2 turned the chain into
+                            //  exec-masked regions and lost the zeroing of one of the four entries -- found by the NA golden test)
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
-                                const bool valid = (i0 + 32 * rg + 16 * mt + 4 * lg + r < n_rows) && (st * 64 + 16 * t + l15 < n_cols);
-                                if (!valid) t2[r] = 0.f, tk[r] = 0.f;
+                                unsigned drop = 0u;
+                                if constexpr (!INTERIOR)
+                                    drop = (unsigned)(i0 + 32 * rg + 16 * mt + 4 * lg + r >= n_rows) | (unsigned)(st * 64 + 16 * t + l15 >= n_cols);
+                                if constexpr (HAS_MISS) drop |= ((t < 2) ? mw[mt][r].x : mw[mt][r].y) & lanebit[t & 1];
+                                t2[r] = drop ? 0.f : t2[r];
+                                tk[r] = drop ? 0.f : tk[r];
                             }
                         }
                         p2[mt] += t2;
@@ -489,9 +508,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
 #pragma unroll
                 for (int t = 0; t < 4; t++) { // column tile t of the stage
                     const int b = t & 1;
-                    if (t < 3) read_h(t + 1, b ^ 1);
+                    if (t < 3) read_h(t + 1, b ^ 1), read_a(t + 1, b ^ 1);
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) da[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[mt][t], identm, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    for (int mt = 0; mt < 2; mt++) da[b][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[b][mt], identm, f32x4{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < 2; mt++) {
                         em[b][mt] = f32x4{0, 0, 0, 0}, ex[b][mt] = f32x4{0, 0, 0, 0};

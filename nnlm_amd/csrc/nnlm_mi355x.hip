@@ -933,9 +933,11 @@ static void prepare_factor16(nnlm_handle *h, int which, unsigned *mb = nullptr, 
     if (fuse) {
         factor16c_kernel<<<h->mpad / 64, 256, 0, h->stream>>>(h->H64, h->mpad, h->m, h->k, mb, nullptr, h->H16c);
         if (!(w_max_in_zero_word && zero_word)) {
-            hipMemsetAsync(h->maxbits, 0, sizeof(unsigned), h->stream);
-            absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits);
-            factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, h->maxbits, h->scal_exp + 2, h->W16c);
+            // (a word of its own: maxbits[0] may be the fixed factor's maximum that the NA flow's row copy reads later, fixed_maxw)
+            unsigned *wmb = h->maxbits + 10;
+            hipMemsetAsync(wmb, 0, sizeof(unsigned), h->stream);
+            absmax_f64_kernel<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, wmb);
+            factor16c_kernel<<<h->npad / 64, 256, 0, h->stream>>>(h->W64, h->npad, h->n, h->k, wmb, h->scal_exp + 2, h->W16c);
         }
     }
 }
@@ -944,10 +946,18 @@ static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
 {
     dim3 grid(p.tiles_x, p.S);
     const int lds = xprod16_err_lds_bytes(NKQ);
-    set_dyn_lds((const void *)xprod16_err_kernel<NKQ>, lds, "xprod16_err_kernel");
-    xprod16_err_kernel<NKQ><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
-                                                                     (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
-                                                                     h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word);
+    if (h->any_missing) {
+        set_dyn_lds((const void *)xprod16_err_kernel<NKQ, true>, lds, "xprod16_err_kernel");
+        xprod16_err_kernel<NKQ, true><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
+                                                                               (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
+                                                                               h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word, h->missT,
+                                                                               h->mpad / 32);
+    } else {
+        set_dyn_lds((const void *)xprod16_err_kernel<NKQ, false>, lds, "xprod16_err_kernel");
+        xprod16_err_kernel<NKQ, false><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
+                                                                                (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
+                                                                                h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word);
+    }
     h->err_zero_word = nullptr;
     h->fused_nb = p.tiles_x * p.S;
 }
@@ -2705,7 +2715,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // Split-fp16 mode without missing values: that half-step's cross product streams A with H_i as its fixed
                 // factor while W_i is still current, so it evaluates the error sums of (W_i, H_i) on the way
                 // (xprod16_err_kernel) and no separate pass over A is needed.
-                h->fuse_err = h->x16 && !h->any_missing && !generic_rank(h);
+                h->fuse_err = h->x16 && !generic_rank(h);
                 h->fused_nb = 0;
                 rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true);
                 h->fuse_err = false;
@@ -2719,6 +2729,8 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // product has finished streaming A -- beside the SWEEP, which is bound by dependent latency and leaves the pipe half idle.
                 // (round 5, bench.py --precision f64: 1.506 against 1.516-1.526 ms per step; the cross product 0.40 instead of 0.69 ms, the error
                 //  block 0.42 instead of 0.34)
+                // (tried for the NA flow of the F32 mode too, scripts/gpu_r5_n.sh: the cross product 0.29 -> 0.16 ms, the Gram + solver kernels
+                //  1.05 -> 1.21 beside errors_f32_kernel -- 2.277 against 2.268 ms per iteration: the work is conserved, not hidden)
                 if (h->prec == NNLM_PREC_F64 && !h->fused_nb) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
             } else
                 h->fused_nb = 0;

@@ -209,3 +209,22 @@ def test_kl_half_steps_take_the_streaming_path_when_their_workspaces_do_not_fit(
     assert s1 == s2
     o = ref.c_nnmf(A, 6, W0, H0, None, None, reg, reg, 2, -1.0, 0, 0, False, inner, 1e-9, method, 2)
     assert relF(W2, o["W"]) < tol and relF(H2, o["H"]) < tol, (relF(W2, o["W"]), relF(H2, o["H"]))
+
+
+@pytest.mark.parametrize("n,m,k", [(200, 100, 5), (255, 128, 5), (256, 127, 5), (129, 128, 5), (300, 190, 20), (513, 130, 40), (777, 333, 50)])
+@pytest.mark.parametrize("frac", [0.0, 0.1])
+def test_error_block_inside_the_cross_product_equals_the_separate_error_kernel(monkeypatch, n, m, k, frac):
+    """F32 mode: the error values of a trace iteration come from the speculative W half-step's cross product (xprod16_err_kernel, with
+    the missing-value bit matrix when A has NA), those of the last iteration from errors_f32_kernel.  Iteration 0's values of a
+    two-iteration run against the one-iteration run's, on shapes whose last row / column tiles are partly padding -- the case in which a
+    compiler-generated exec-mask region once dropped the mask of one of a lane's four entries (round 5)."""
+    monkeypatch.setenv("NNLM_PRECISION", "f32")
+    rng = np.random.default_rng(n * 1000 + m)
+    A, W0, H0 = rng.random((n, m)), rng.random((n, k)), rng.random((k, m))
+    if frac:
+        A.ravel()[rng.choice(A.size, int(A.size * frac), replace=False)] = np.nan
+    z = [0.0, 0.0, 0.0]
+    r1 = nnlm_amd.c_nnmf(A, k, W0, H0, None, None, z, z, 1, -1.0, 1, 0, False, 50, 1e-9, 1, 1)
+    r2 = nnlm_amd.c_nnmf(A, k, W0, H0, None, None, z, z, 2, -1.0, 1, 0, False, 50, 1e-9, 1, 1)
+    assert abs(r2["mse_error"][0] - r1["mse_error"][0]) <= 1e-7 * r1["mse_error"][0]
+    assert abs(r2["mkl_error"][0] - r1["mkl_error"][0]) <= 1e-6 * abs(r1["mkl_error"][0]) + 1e-9
