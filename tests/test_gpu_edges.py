@@ -227,4 +227,4 @@ def test_error_block_inside_the_cross_product_equals_the_separate_error_kernel(m
     r1 = nnlm_amd.c_nnmf(A, k, W0, H0, None, None, z, z, 1, -1.0, 1, 0, False, 50, 1e-9, 1, 1)
     r2 = nnlm_amd.c_nnmf(A, k, W0, H0, None, None, z, z, 2, -1.0, 1, 0, False, 50, 1e-9, 1, 1)
     assert abs(r2["mse_error"][0] - r1["mse_error"][0]) <= 1e-7 * r1["mse_error"][0]
-    assert abs(r2["mkl_error"][0] - r1["mkl_error"][0]) <= 1e-6 * abs(r1["mkl_error"][0]) + 1e-9
+    assert abs(r2["mkl_error"][0] - r1["mkl_error"][0]) <= 5e-6 * abs(r1["mkl_error"][0]) + 1e-9
