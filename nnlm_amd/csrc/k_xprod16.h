@@ -60,8 +60,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
-    const int j0 = blockIdx.x * XPROD_TN_BJ;
-    int st0 = stage_begin + blockIdx.y * stages_per_split;
+    // (EXP bit 4, scripts/exp/xerr_exp.hip: tiles, slabs and stages in descending order -- does a pass find the end of the previous one in the infinity cache?)
+    const int j0 = ((EXP & 16) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * XPROD_TN_BJ;
+    int st0 = stage_begin + ((EXP & 16) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * stages_per_split;
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
 
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
     const unsigned long long baseA = xp_uniform64(A16 + (size_t)j0 * lda), baseY = xp_uniform64(Y16);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     auto issue = [&](int st, int bi) {
-        const unsigned long long c0b = (unsigned long long)((EXP & 4) && st > st0 + 1 ? st0 : st) * 256ull; // byte offset of the chunk
+        const int sta = (EXP & 16) ? st1 - 1 - (st - st0) : st;
+        const unsigned long long c0b = (unsigned long long)((EXP & 4) && st > st0 + 1 ? st0 : sta) * 256ull; // byte offset of the chunk
         const unsigned dst = lds0 + (unsigned)bi * (unsigned)BUF + (unsigned)wave * 1024u;
 #pragma unroll
         for (int i = 0; i < XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES; i++)

@@ -78,6 +78,13 @@ int main(int argc, char **argv)
             const int lds = xprod_tn_lds_bytes(KP);
             CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+        } else if (v == 60 || v == 61) { // 60: ascending and descending passes alternate over the same buffer; 61: two ascending passes (control)
+            const int lds = xprod_tn_lds_bytes(KP);
+            CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+            if (v == 60) xprod16_tn_kernel<4, 16><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+            else xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
         } else if (v == 2) {
             const int lds = xprod_tn_lds_bytes(KP);
             CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
