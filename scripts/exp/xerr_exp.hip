@@ -40,6 +40,26 @@ __global__ void to_kqc(const uint32_t *Y16, size_t len, uint32_t *Xc)
     dst[64 + q] = row[64 + (c & 63)];
 }
 
+// reads (and drops) the first `xst` stages of every block of a (tiles x S) plan of the cross product: rows of 256 bytes per stage
+// and image row, so that they are in the memory-side cache when the cross product starts
+__global__ __launch_bounds__(256) void mall_prefetch_kernel(const uint32_t *__restrict__ A16, int lda, int tiles, int S, int sps, int stages, int xst, int nblk, unsigned *sink)
+{
+    // one request = 16 bytes per lane; a wavefront covers 4 rows x 256 bytes
+    const size_t total = (size_t)nblk * xst * 32; // 1 KB pieces: 32 per block and stage
+    unsigned acc = 0;
+    for (size_t pc = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pc < total; pc += (size_t)gridDim.x * 4) {
+        const int piece = (int)(pc % 32), st = (int)((pc / 32) % xst), blk = (int)(pc / 32 / xst);
+        const int tile = blk % tiles, slab = blk / tiles;
+        const int stage = slab * sps + st;
+        if (stage >= stages) continue;
+        const int lane = threadIdx.x & 63, row = tile * 128 + piece * 4 + (lane >> 4);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 v = *(const u4 *)(A16 + (size_t)row * lda + (size_t)stage * 64 + (lane & 15) * 4);
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 20000, m = argc > 2 ? atoi(argv[2]) : 10000, variant = argc > 3 ? atoi(argv[3]) : 0;
@@ -64,6 +84,7 @@ int main(int argc, char **argv)
     to_kqc<<<(unsigned)(((size_t)npad * 64 + 255) / 256), 256>>>(W16, npad, W16c);
     CK(hipDeviceSynchronize());
     dim3 grid(tiles_x, S);
+    hipEvent_t eA, eB; CK(hipEventCreate(&eA)); CK(hipEventCreate(&eB));
     const size_t slab = (size_t)KP * npad;
     auto launch = [&](int v, double *C, double *P) -> int {
         if (v == 0) {
@@ -78,6 +99,16 @@ int main(int argc, char **argv)
             const int lds = xprod_tn_lds_bytes(KP);
             CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+        } else if (v >= 70 && v <= 73) { // the memory-side cache as a prefetch target: 70 pass over another buffer, then the timed pass; 71-73: + prefetch of 16 / 24 / 32 stages
+            static uint32_t *A2 = nullptr; static unsigned *sink = nullptr;
+            if (!A2) { CK(hipMalloc(&A2, (size_t)npad * mpad * 4)); CK(hipMemset(A2, 0, (size_t)npad * mpad * 4)); CK(hipMalloc(&sink, 4)); }
+            const int lds = xprod_tn_lds_bytes(KP);
+            CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A2, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+            if (v > 70) mall_prefetch_kernel<<<1024, 256>>>(A16T, mpad, tiles_x, S, sps, stages, 8 + 8 * (v - 70), 256, sink);
+            CK(hipEventRecord(eA));
+            xprod16_tn_kernel<4><<<grid, XPROD_THREADS, lds>>>(A16T, mpad, Y16, mpad, C, npad, slab, 0, stages, sps, scal);
+            CK(hipEventRecord(eB));
         } else if (v == 60 || v == 61) { // 60: ascending and descending passes alternate over the same buffer; 61: two ascending passes (control)
             const int lds = xprod_tn_lds_bytes(KP);
             CK(hipFuncSetAttribute((const void *)xprod16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -107,6 +138,7 @@ int main(int argc, char **argv)
         if (launch(variant, Cx, partial)) return 1;
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (variant >= 70 && variant <= 73) CK(hipEventElapsedTime(&ms, eA, eB)); // (the second pass alone)
         tms.push_back(ms);
     }
     std::sort(tms.begin(), tms.end());
