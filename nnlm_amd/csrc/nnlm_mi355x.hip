@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -292,6 +293,73 @@ extern "C" unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace)
 }
 
 static int g_debug_cus = 0; // nnlm_debug_set_cus: compute units the launch policies of new handles count (0 = the device's)
+// Pinned bounce buffers of nnlm_set_matrix, kept between calls.  Pinning costs ~0.3 ms per MB: two fresh 64 MB buffers were ~40 ms of EVERY
+// upload (half of config 2's 78 ms, most of the 53 ms an 80 MB matrix took -- scripts/gpu_call_breakdown.py).  One pair per process, taken
+// by the call that finds it free (a concurrent upload on another thread allocates its own and frees it), released at exit.
+static std::mutex g_bounce_mu;
+static double *g_bounce[2] = {nullptr, nullptr};
+static size_t g_bounce_bytes = 0;
+static bool g_bounce_busy = false, g_bounce_atexit = false;
+static void bounce_release_at_exit()
+{
+    // (the HIP runtime may already be gone when exit handlers run: errors are ignored)
+    for (int b = 0; b < 2; b++)
+        if (g_bounce[b]) (void)hipHostFree(g_bounce[b]);
+    g_bounce[0] = g_bounce[1] = nullptr;
+    g_bounce_bytes = 0;
+}
+// both buffers of at least `bytes`, or false (none to be had / the pair is in use): *cached tells the caller whether to give them back
+static bool bounce_acquire(size_t bytes, double *out[2], bool *cached)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_bounce_mu);
+        if (!g_bounce_busy) {
+            if (g_bounce_bytes < bytes) {
+                for (int b = 0; b < 2; b++)
+                    if (g_bounce[b]) (void)hipHostFree(g_bounce[b]);
+                g_bounce[0] = g_bounce[1] = nullptr;
+                g_bounce_bytes = 0;
+                if (hipHostMalloc(&g_bounce[0], bytes) != hipSuccess || hipHostMalloc(&g_bounce[1], bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    for (int b = 0; b < 2; b++)
+                        if (g_bounce[b]) (void)hipHostFree(g_bounce[b]);
+                    g_bounce[0] = g_bounce[1] = nullptr;
+                    return false;
+                }
+                g_bounce_bytes = bytes;
+                if (!g_bounce_atexit) {
+                    g_bounce_atexit = true;
+                    atexit(bounce_release_at_exit);
+                }
+            }
+            g_bounce_busy = true;
+            out[0] = g_bounce[0], out[1] = g_bounce[1];
+            *cached = true;
+            return true;
+        }
+    }
+    *cached = false; // another upload holds the pair: buffers of this call's own
+    out[0] = out[1] = nullptr;
+    if (hipHostMalloc(&out[0], bytes) != hipSuccess || hipHostMalloc(&out[1], bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int b = 0; b < 2; b++)
+            if (out[b]) (void)hipHostFree(out[b]);
+        out[0] = out[1] = nullptr;
+        return false;
+    }
+    return true;
+}
+static void bounce_give_back(double *buf[2], bool cached)
+{
+    if (cached) {
+        std::lock_guard<std::mutex> lk(g_bounce_mu);
+        g_bounce_busy = false;
+    } else
+        for (int b = 0; b < 2; b++)
+            if (buf[b]) (void)hipHostFree(buf[b]);
+    buf[0] = buf[1] = nullptr;
+}
+
 static size_t g_debug_alloc_limit = 0; // nnlm_debug_alloc_limit: matrix-sized KL workspaces beyond this many bytes "do not fit" (0 = no limit)
 
 // Matrix-sized workspaces of the KL solvers (starting states of all columns, transposed copy of A, streaming scratch): the callers have
@@ -518,15 +586,13 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
     double *hp[2] = {nullptr, nullptr}; // pinned: the prep pass's partial sums of each slot
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     int rc = NNLM_OK;
-    bool pinned = true;
+    // (matrices of a few MB go through the runtime's pageable path: its own staging buffers are pinned already)
+    bool bounce_cached = false;
+    bool pinned = (size_t)n * m * 8 >= ((size_t)4 << 20) && bounce_acquire(chunk_bytes, bounce, &bounce_cached);
     for (int b = 0; b < 2 && rc == NNLM_OK; b++) {
         if (hipMalloc(&stage[b], chunk_bytes) != hipSuccess) rc = fail(h, NNLM_ERR_HIP, "nnlm_set_matrix: staging buffer (%zu bytes)", chunk_bytes);
         else if (hipHostMalloc(&hp[b], 3 * prep_blocks * sizeof(double)) != hipSuccess || hipEventCreateWithFlags(&ev_done[b], hipEventDisableTiming) != hipSuccess)
             rc = fail(h, NNLM_ERR_HIP, "nnlm_set_matrix: pinned result buffer / event");
-        else if (pinned && hipHostMalloc(&bounce[b], chunk_bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            pinned = false; // (no pinned memory to be had: the runtime's pageable path)
-        }
     }
     unsigned nthreads = std::thread::hardware_concurrency();
     nthreads = nthreads >= 16 ? 8u : (nthreads >= 4 ? nthreads / 2 : 1u);
@@ -599,9 +665,9 @@ extern "C" int nnlm_set_matrix(nnlm_handle *h, const double *A, int n, int m)
         if (pending[b] && rc == NNLM_OK) rc = collect(b);
     }
     hipStreamSynchronize(h->stream);
+    if (pinned) bounce_give_back(bounce, bounce_cached);
     for (int b = 0; b < 2; b++) {
         hipFree(stage[b]);
-        if (bounce[b]) hipHostFree(bounce[b]);
         if (hp[b]) hipHostFree(hp[b]);
         if (ev_done[b]) hipEventDestroy(ev_done[b]);
     }
