@@ -139,6 +139,7 @@ struct nnlm_handle {
     double *What64 = nullptr;    // the same in fp64 for the strict mode (wh_store64_kernel)
     uint32_t *W16c = nullptr, *H16c = nullptr; // kq-contiguous split copies [npad][2][64], [mpad][2][64] (fused error block)
     bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
+    int cus_device = 0;          // the device's CU count (cus may be the test hook's)
     int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
     unsigned *err_zero_word = nullptr; // the fused kernel clears this word (max|x| of the sweep that follows it; see factor16_fold_err_kernel)
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
@@ -389,6 +390,38 @@ extern "C" int nnlm_debug_set_cus(int cus)
     return NNLM_OK;
 }
 
+// The streams, events and small buffers of a destroyed handle wait here for the next nnlm_create on the same device (one set per process):
+// creating and destroying them is 5 + 5 ms of every one-shot call -- half of a 200 x 100 nnmf() of 100 iterations (scripts/gpu_call_breakdown.py).
+// The handle itself is always a fresh object: no state of a previous call survives, only resources do.
+struct HandleRes {
+    bool valid = false;
+    int device = -1, cus = 0;
+    hipStream_t stream = nullptr, stream_e = nullptr;
+    hipEvent_t ev_hdone = nullptr, ev_err = nullptr, ev_xdone = nullptr;
+    double *scal = nullptr, *host_res = nullptr, *sweepq_img = nullptr;
+    unsigned long long *sweeps = nullptr, *sweeps_tmp = nullptr;
+    unsigned *maxbits = nullptr;
+    int *scal_exp = nullptr;
+};
+static std::mutex g_res_mu;
+static HandleRes g_res;
+static bool g_res_atexit = false;
+static void handle_res_destroy(HandleRes &r)
+{
+    (void)hipFree(r.scal), (void)hipFree(r.sweeps), (void)hipHostFree(r.host_res), (void)hipFree(r.sweeps_tmp), (void)hipFree(r.sweepq_img);
+    (void)hipFree(r.maxbits), (void)hipFree(r.scal_exp);
+    if (r.ev_hdone) (void)hipEventDestroy(r.ev_hdone);
+    if (r.ev_err) (void)hipEventDestroy(r.ev_err);
+    if (r.ev_xdone) (void)hipEventDestroy(r.ev_xdone);
+    if (r.stream_e) (void)hipStreamDestroy(r.stream_e);
+    if (r.stream) (void)hipStreamDestroy(r.stream);
+    r = HandleRes{};
+}
+static void handle_res_release_at_exit()
+{
+    if (g_res.valid) handle_res_destroy(g_res); // (errors ignored: the runtime may be shutting down)
+}
+
 extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
 {
     if (!out) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: out is NULL");
@@ -400,6 +433,32 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: no HIP device available (%s); libnnlm_mi355x has no CPU path", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (device < 0 || device >= ndev) return fail(nullptr, NNLM_ERR_ARG, "nnlm_create: device %d out of range (0..%d)", device, ndev - 1);
     HIPCHK(nullptr, hipSetDevice(device));
+    HandleRes res;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (g_res.valid && g_res.device == device) {
+            res = g_res;
+            g_res = HandleRes{};
+        }
+    }
+    if (res.valid) { // the resources of a handle this process destroyed earlier (same device: the architecture check has been made)
+        nnlm_handle *h = new nnlm_handle();
+        h->device = device;
+        h->prec = precision;
+        h->cus = h->cus_device = res.cus;
+        if (g_debug_cus > 0) h->cus = g_debug_cus;
+        h->stream = res.stream, h->stream_e = res.stream_e;
+        h->ev_hdone = res.ev_hdone, h->ev_err = res.ev_err, h->ev_xdone = res.ev_xdone;
+        h->scal = res.scal, h->sweeps = res.sweeps, h->host_res = res.host_res, h->sweeps_tmp = res.sweeps_tmp, h->sweepq_img = res.sweepq_img;
+        h->maxbits = res.maxbits, h->scal_exp = res.scal_exp;
+        hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
+        hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
+        hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream);
+        hipStreamSynchronize(h->stream);
+        h->x16 = x16_enabled(precision);
+        *out = h;
+        return NNLM_OK;
+    }
     hipDeviceProp_t prop;
     HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -408,6 +467,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     h->device = device;
     h->prec = precision;
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->cus_device = h->cus;
     if (g_debug_cus > 0) h->cus = g_debug_cus; // test hook (nnlm_debug_set_cus): the sweep's launch policy at small sizes
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
@@ -530,19 +590,25 @@ extern "C" void nnlm_destroy(nnlm_handle *h)
     }
     free_factors(h);
     free_matrix(h);
-    hipFree(h->scal);
-    hipFree(h->sweeps);
-    hipHostFree(h->host_res);
-    hipFree(h->sweeps_tmp);
-    hipFree(h->sweepq_img);
-    hipFree(h->maxbits);
-    hipFree(h->scal_exp);
-    if (h->ev_hdone) hipEventDestroy(h->ev_hdone);
-    if (h->ev_err) hipEventDestroy(h->ev_err);
-    if (h->ev_xdone) hipEventDestroy(h->ev_xdone);
-    if (h->stream_e) hipStreamDestroy(h->stream_e);
-    if (h->stream) hipStreamDestroy(h->stream);
+    HandleRes res;
+    res.valid = true, res.device = h->device, res.cus = h->cus_device;
+    res.stream = h->stream, res.stream_e = h->stream_e;
+    res.ev_hdone = h->ev_hdone, res.ev_err = h->ev_err, res.ev_xdone = h->ev_xdone;
+    res.scal = h->scal, res.sweeps = h->sweeps, res.host_res = h->host_res, res.sweeps_tmp = h->sweeps_tmp, res.sweepq_img = h->sweepq_img;
+    res.maxbits = h->maxbits, res.scal_exp = h->scal_exp;
     delete h;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (!g_res.valid && hipGetLastError() == hipSuccess) { // (the streams are idle: sync_all above; a sticky error keeps nothing)
+            g_res = res;
+            res.valid = false;
+            if (!g_res_atexit) {
+                g_res_atexit = true;
+                atexit(handle_res_release_at_exit);
+            }
+        }
+    }
+    if (res.valid) handle_res_destroy(res);
 }
 
 // ---------------------------------------------------------------------------------------------
