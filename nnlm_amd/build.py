@@ -2,10 +2,12 @@
 
 The library is a handful of translation units (nnlm_amd/csrc/*.hip) compiled in parallel and linked into one shared object: the SCD
 sweep kernels of k_sweep_q.h (one heavy instantiation per block count, mask and arithmetic mode) take as long as everything else
-together, so they have units of their own (tu_sweepq.hip, tu_sweepqw.hip)."""
+together, so they have units of their own (tu_sweepq.hip, tu_sweepqw.hip, tu_sweepf.hip)."""
 from __future__ import annotations
 
+import hashlib
 import os
+import signal
 import subprocess
 import sys
 
@@ -46,23 +48,35 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA C/D operands in VGPRs (gfx950 has a unified register file); the sweep kernel
     # reads and rewrites single accumulator entries between MFMAs and would otherwise shuttle whole tiles VGPR<->AGPR
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
+    # an object is fresh when it is newer than its unit and every header the unit includes AND was built by this compiler with these
+    # flags (recorded next to it); objects are written under a temporary name and renamed on success, so a killed compiler cannot leave
+    # a truncated file that the next run would trust
+    stamp = hashlib.sha256((" ".join([os.path.realpath(hipcc)] + flags)).encode()).hexdigest()
     procs, fresh = [], []
     for src in units():  # every stale unit at once: a few processes, each minutes long
         obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
-        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in unit_deps(src)):
+        tag = obj + ".flags"
+        same_flags = os.path.exists(tag) and open(tag).read() == stamp
+        if not force and same_flags and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in unit_deps(src)):
             fresh.append(obj)  # (the unit and its headers are older than its object)
             continue
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj + ".tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, obj, subprocess.Popen(cmd)))
+        procs.append((cmd, obj, subprocess.Popen(cmd, start_new_session=True)))  # (own process group: hipcc is a wrapper around clang children)
     objs = []
     for cmd, obj, p in procs:
         if p.wait() != 0:
             for _, _, q in procs:
                 if q.poll() is None:
-                    q.kill()
+                    try:
+                        os.killpg(q.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.replace(obj + ".tmp", obj)
+        with open(obj + ".flags", "w") as f:
+            f.write(stamp)
         objs.append(obj)
     objs += fresh
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

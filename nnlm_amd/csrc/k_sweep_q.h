@@ -140,14 +140,15 @@ constexpr SqSched sq_sched(int NL)
 
 // What every sweep workgroup leaves behind from its final x image xl[columns][KP + 2] (columns col_base .. col_base + columns - 1): the
 // factor outputs, max|x| and the Gram partial sums of its columns (slab `slab_idx`) for the next half-step.  COLS > 0: that many
-// columns, known at compile time (plain form: 64); COLS = 0: `ncl` of them (persistent form: 16 G, a multiple of 16).
-template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(const SweepArgs &a, const double *xl, int ncl, int col_base, int slab_idx)
+// columns, known at compile time (plain form: 64); COLS = 0: `ncl` of them (persistent form: 16 G, a multiple of 16).  NWAVES wavefronts
+// in the workgroup (4 everywhere but the fp32-chain kernel's two-per-SIMD form, k_sweep_f.h).
+template <int NT, int COLS, int NWAVES = 4> __device__ __forceinline__ void sweepq_epilogue(const SweepArgs &a, const double *xl, int ncl, int col_base, int slab_idx)
 {
-    constexpr int KP = 16 * NT, XS = KP + 2;
+    constexpr int KP = 16 * NT, XS = KP + 2, NTHREADS = 64 * NWAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
     const int ncols_wg = COLS ? COLS : ncl;
     float xmax = 0.0f;
-    for (int e = tid; e < ncols_wg * KP; e += SWEEPQ_THREADS) {
+    for (int e = tid; e < ncols_wg * KP; e += NTHREADS) {
         const int q = e / ncols_wg, c = e % ncols_wg, ecol = col_base + c;
         if (q < k && ecol < a.ncols) {
             const double xv = xl[c * XS + q];
@@ -174,7 +175,7 @@ template <int NT, int COLS> __device__ __forceinline__ void sweepq_epilogue(cons
         for (int ta = 0; ta < NT; ta++)
 #pragma unroll
             for (int tb = ta; tb < NT; tb++) {
-                if ((tix++ & 3) != wave) continue;
+                if ((tix++ % NWAVES) != wave) continue;
                 f64x4 g = f64x4{0, 0, 0, 0};
 #pragma unroll(COLS ? COLS / 4 : 1)
                 for (int s4 = 0; s4 < ncols_wg / 4; s4++) {

@@ -1269,16 +1269,39 @@ static int sweep_lanes_per_column(int ncols)
 // fp64 mode: the reference's arithmetic (correctly rounded mu / G[q][q]).
 static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX; }
 
-// (the instantiations of sweep_scd_q_kernel / sweep_scd_qw_kernel -- 64 + 64 heavy ones -- live in translation units of their own,
-//  tu_sweepq.hip / tu_sweepqw.hip, compiled next to this one: tu_sweepq.h)
+// (the instantiations of sweep_scd_q_kernel / sweep_scd_qw_kernel / sweep_scd_f_kernel -- 64 heavy ones each -- live in translation units of
+//  their own, tu_sweepq.hip / tu_sweepqw.hip / tu_sweepf.hip, compiled next to this one: tu_sweepq.h)
+// fp32-operand mode: the fp32-chain kernel (k_sweep_f.h).  One wavefront per 16 columns; four per workgroup (one per SIMD) while the
+// launch has at most one wavefront per SIMD of the device, eight (two per SIMD, 128 columns per workgroup) beyond -- the instruction
+// streams of two wavefronts interleave where a lone one leaves every second issue slot empty.  Reads a.Graw; no operand image.
+static void launch_sweep_f(nnlm_handle *h, const SweepArgs &a)
+{
+    const int ncols = a.ncols - a.col0, NB = (a.k + 3) / 4;
+    h->sweep_wgs = 0;
+    h->pack_ready = false;
+    if (ncols <= 0) return;
+    const int ngroups = (ncols + 15) / 16, simds = 4 * h->cus;
+    const int NW = ngroups > simds ? 8 : 4;
+    const int nb = (ncols + 16 * NW - 1) / (16 * NW);
+    h->sweep_wgs = nb;
+    h->sweep_form[h->cur_which] = 2;
+    h->sweep_groups[h->cur_which] = NW;
+    const hipError_t ea = nnlm_tu_sweep_f(a, nb, NB, NW, h->stream);
+    if (ea != hipSuccess && g_attr_err == hipSuccess) {
+        g_attr_err = ea;
+        g_attr_what = "sweep_scd_f_kernel";
+    }
+}
+
 static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
 {
+    if (h->prec == NNLM_PREC_F32) return launch_sweep_f(h, a);
     int nb = (a.ncols - a.col0 + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
     const int NB = (a.k + 3) / 4;
     h->sweep_wgs = 0;
     if (nb <= 0) return;
     if (!h->pack_ready)
-        sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img, h->prec == NNLM_PREC_F64 ? 1 : 0);
+        sweepq_pack_kernel<<<8, 256, 0, h->stream>>>(a.Graw, a.KPg, a.k, a.r0, a.r1, NB, h->sweepq_img, 1);
     h->pack_ready = false;
     // Launch policy.  A SIMD runs one wavefront (16 columns) of this sweep at full speed and a second one adds its whole time: the plain
     // form costs ceil(groups / SIMDs) rounds of S sweeps.  The persistent form gives every CU G column groups, shared by its four
@@ -1290,7 +1313,7 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     if (ngroups > simds && a.max_iter >= 4) {
         long best = ((long)ngroups + simds - 1) / simds * 4; // the plain form
         for (int g = 5; g <= SWEEPQ_WRAP_MAXG; g++) {
-            if (sweepqw_lds_bytes(h->KP, NB, h->prec == NNLM_PREC_F64, g) > (size_t)160 * 1024) break;
+            if (sweepqw_lds_bytes(h->KP, NB, true, g) > (size_t)160 * 1024) break;
             const long wgs = ((long)ngroups + g - 1) / g, rounds = (wgs + h->cus - 1) / h->cus;
             if (rounds * g < best) best = rounds * g, G = g;
         }
@@ -1299,8 +1322,7 @@ static void launch_sweep_q(nnlm_handle *h, const SweepArgs &a)
     h->sweep_wgs = nb;
     h->sweep_form[h->cur_which] = G ? 1 : 0;
     h->sweep_groups[h->cur_which] = G ? G : 4;
-    const bool strict = h->prec == NNLM_PREC_F64;
-    const hipError_t ea = G ? nnlm_tu_sweep_qw(a, h->sweepq_img, nb, NB, strict, G, h->stream) : nnlm_tu_sweep_q(a, h->sweepq_img, nb, NB, strict, h->stream);
+    const hipError_t ea = G ? nnlm_tu_sweep_qw(a, h->sweepq_img, nb, NB, true, G, h->stream) : nnlm_tu_sweep_q(a, h->sweepq_img, nb, NB, true, h->stream);
     if (ea != hipSuccess && g_attr_err == hipSuccess) {
         g_attr_err = ea;
         g_attr_what = G ? "sweep_scd_qw_kernel" : "sweep_scd_q_kernel";
@@ -1971,9 +1993,9 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         if (fastsw && sg_which == (which == 1 ? 0 : 1)) {
             {
                 ProfScope ps(h, P_GRAM, h->stream);
-                // (the fold of the Gram partial sums also writes the operand image of this half-step's sweep: no sweepq_pack_kernel launch)
                 SweepImg im;
-                im.img = h->sweepq_img, im.NB = (h->k + 3) / 4, im.NP = sweepq_np(im.NB, false), im.k = h->k, im.r0 = reg[0], im.r1 = reg[1];
+                im.img = nullptr; // (fp32-operand mode: sweep_scd_f_kernel builds its operands from Graw itself -- no image)
+                im.NB = (h->k + 3) / 4, im.NP = sweepq_np(im.NB, false), im.k = h->k, im.r0 = reg[0], im.r1 = reg[1];
                 if (h->fuse_err && which == 0 && sg_other == 0) {
                     // trace iteration, max|W| still in the word W's sweep left it in: the split copies of H (rows and kq-contiguous) and of
                     // W (kq-contiguous) and the fold in one launch; the fused kernel clears that word for this half-step's sweep

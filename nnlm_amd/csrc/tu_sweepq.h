@@ -9,3 +9,5 @@
 hipError_t nnlm_tu_sweep_q(const SweepArgs &a, const double *img, int nb, int NB, bool strict, hipStream_t st);
 // nb workgroups of G column groups of 16 (one workgroup per CU)
 hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int NB, bool strict, int G, hipStream_t st);
+// fp32-operand mode (k_sweep_f.h, tu_sweepf.hip): nb workgroups of NW = 4 or 8 wavefronts of 16 columns; reads a.Graw, no operand image
+hipError_t nnlm_tu_sweep_f(const SweepArgs &a, int nb, int NB, int NW, hipStream_t st);

@@ -12,8 +12,8 @@ template <int NT, int NB, bool M, bool S> static hipError_t launch_k(const Sweep
 }
 template <int NT, int NB> static hipError_t launch_m(const SweepArgs &a, const double *img, int nb, bool strict, int G, hipStream_t st)
 {
-    if (strict) return a.mask ? launch_k<NT, NB, true, true>(a, img, nb, G, st) : launch_k<NT, NB, false, true>(a, img, nb, G, st);
-    return a.mask ? launch_k<NT, NB, true, false>(a, img, nb, G, st) : launch_k<NT, NB, false, false>(a, img, nb, G, st);
+    (void)strict; // (the fp32-operand mode has its own kernel since round 6, k_sweep_f.h / tu_sweepf.hip: only the strict arithmetic is instantiated here)
+    return a.mask ? launch_k<NT, NB, true, true>(a, img, nb, G, st) : launch_k<NT, NB, false, true>(a, img, nb, G, st);
 }
 hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int NB, bool strict, int G, hipStream_t st)
 {

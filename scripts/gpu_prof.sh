@@ -1,18 +1,21 @@
 #!/bin/bash
-# rocprofv3 passes over the bench command: kernel-trace stats, then HBM byte counters (separate passes).
-set -x
-mkdir -p gpurun_out/prof
+# One gpurun call: rocprofv3 kernel stats of one bench configuration (and, with PMC=1, the HBM byte counters in separate passes).
+# usage: scripts/gpu_prof.sh TAG CONFIG PRECISION [STEPS] [extra bench.py arguments]      e.g.  gpu_prof.sh r06_cfg2 2 f32 20
+# -> gpurun_out/prof/${TAG}_bench_under_rocprof.json, ${TAG}_kernel_stats.csv (+ ${TAG}_pmc_hbm_summary.txt); copy what is to be kept into profiles/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r01}
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/$TAG -o trace -- python $R/bench.py --steps 20 --warmup 2 --cpu-iters 0 > $R/gpurun_out/prof/${TAG}_bench.json 2> $R/gpurun_out/prof/${TAG}_trace.err; echo "trace exit=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof/$TAG -o fetch -- python $R/bench.py --steps 6 --warmup 1 --cpu-iters 0 > /dev/null 2> $R/gpurun_out/prof/${TAG}_fetch.err; echo "fetch exit=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof/$TAG -o write -- python $R/bench.py --steps 6 --warmup 1 --cpu-iters 0 > /dev/null 2> $R/gpurun_out/prof/${TAG}_write.err; echo "write exit=$?"
-cd $R
-ls -la gpurun_out/prof/$TAG
-head -30 gpurun_out/prof/$TAG/*kernel_stats.csv
-python scripts/pmc_summary.py gpurun_out/prof/$TAG || true
-# keep the merged output small: the per-dispatch traces are large
-find gpurun_out/prof/$TAG -name "*kernel_trace.csv" -size +2M -delete
-find gpurun_out/prof/$TAG -name "*.db" -delete
+TAG=$1; CFG=$2; PREC=$3; STEPS=${4:-10}; shift 4
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+BENCH="python $R/bench.py --config $CFG --precision $PREC --steps $STEPS --warmup 2 --cpu-iters 0 --repeats 1 --others 0 --call 0 $*"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG} -o p -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err; echo "rocprof exit=$?")
+f=$(find $OUT/prof_${TAG} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats.csv && head -16 "$f" | cut -c1-170
+rm -rf $OUT/prof_${TAG}
+if [ "$PMC" == "1" ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- $BENCH --steps 6 > /dev/null 2> $OUT/${TAG}_pmc_$c.err; echo "pmc $c exit=$?")
+  done
+  python $R/scripts/pmc_summary.py $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE > $OUT/${TAG}_pmc_hbm_summary.txt 2>&1 || true
+  tail -20 $OUT/${TAG}_pmc_hbm_summary.txt
+  rm -rf $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+fi

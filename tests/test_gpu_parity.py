@@ -54,6 +54,11 @@ def test_half_step_matches_oracle(pname, prec, tol, method, shape):
     inner = 5 if method < 3 else 2
     if method >= 3 and pname == "f32":
         tol = 1e-4  # F32 mode runs the KL solvers with fp32 state and v_rcp_f32 quotients (k_kl.h, kl_fast_kernel)
+    if method == 1 and pname == "f32":
+        # round 6: the SCD chain runs on fp32 state (k_sweep_f.h).  Its error scales with how far the half-step moves a column from its
+        # start: ~5e-5 from uniformly random factors as here (the worst case), 2e-7 from a warm start (scripts/exp/sweepf_exp.hip WARM=1),
+        # 7e-6 after 20 iterations at full size (tests/test_gpu_fullsize.py) -- the mode's contract is 1e-4 (BASELINE.json north_star)
+        tol = 1e-4
     with nnlm_amd.Handle(0, prec) as h:
         h.set_matrix(A)
         h.set_factors(k, W0, H0)
@@ -66,7 +71,7 @@ def test_half_step_matches_oracle(pname, prec, tol, method, shape):
         _, H1 = h.get_factors()
         s2 = h.take_sweeps()
         H_ref, it2 = ref.update(H0, Wt_ref, A, None, reg, inner, 1e-9, method)
-        assert relF(H1, H_ref) < 10 * tol
+        assert relF(H1, H_ref) < (2e-4 if (method == 1 and pname == "f32") else 10 * tol)
         assert np.all(W1 >= 0) and np.all(H1 >= 0)
         if pname == "f64":
             assert (s1, s2) == (it1, it2)
@@ -102,7 +107,8 @@ def test_half_step_is_insensitive_to_the_magnitudes_of_A_and_the_factors(scale_a
         A[rng.random((n, m)) < 0.15] = np.nan
     W0 = np.sqrt(scale_a) / scale_f * rng.random((n, k))
     H0 = scale_f * np.sqrt(scale_a) * rng.random((k, m))
-    for prec, tol in ((_lib.PREC_F32, 2e-5), (_lib.PREC_F64, 1e-10)):
+    # (F32 mode, dense: the fp32-chain sweep's cold-start error, see test_half_step_matches_oracle; with missing entries the fp64 column solver)
+    for prec, tol in ((_lib.PREC_F32, 2e-5 if missing else 1e-4), (_lib.PREC_F64, 1e-10)):
         with nnlm_amd.Handle(0, prec) as h:
             h.set_matrix(A)
             h.set_factors(k, W0, H0)

@@ -1,10 +1,13 @@
-"""The persistent ("wrap-around") form of the SCD sweep (k_sweep_q.h, sweep_scd_qw_kernel): between one and two wavefronts of 16
+"""Launch forms of the SCD sweep.  Strict fp64 mode: the persistent ("wrap-around") form (k_sweep_q.h, sweep_scd_qw_kernel) -- between one and two wavefronts of 16
 columns per SIMD the launch gives every CU G = 5 .. 7 column groups, which its four wavefronts share by McNaughton's rule -- a group
 cut by a piece boundary is started by one wavefront and finished by another, its state handed over through LDS.  Same arithmetic per
 column as the plain form, so the results must be BIT-IDENTICAL to it: the device is made to look small (nnlm_debug_set_cus, read by
 nnlm_create) so that a few hundred columns take the persistent form, and the same problem is run on the plain form for comparison;
 both are also held against the oracle.  The benchmark's W half-step (20000 columns on 256 CUs: G = 5) takes this form at full size
-(tests/test_gpu_fullsize.py)."""
+(tests/test_gpu_fullsize.py).
+fp32-operand mode (round 6): the fp32-chain kernel (k_sweep_f.h, sweep_scd_f_kernel; nnlm_get_info form 2) with workgroups of four
+wavefronts (one per SIMD) up to one wavefront per SIMD of the device and of eight (two per SIMD) beyond: the same operations per column
+either way, so the same bit-identity holds between a device made to look small and the real one."""
 import os
 import sys
 
@@ -81,11 +84,15 @@ def test_launch_policy_picks_the_cheapest_form(monkeypatch):
     count per workgroup that costs least beyond (costs in quarter sweeps: plain ceil(groups / SIMDs) * 4, persistent rounds * G)."""
     rng = np.random.default_rng(5)
     k = 8
-    for cus, n, want in [(2, 128, (0, 4)), (2, 150, (1, 5)), (1, 144, (1, 9)), (1, 128, (0, 4)), (2, 400, (1, 7)), (2, 304, (1, 5)), (2, 280, (1, 9))]:
+    cases = [(_lib.PREC_F64, cus, n, want) for cus, n, want in
+             [(2, 128, (0, 4)), (2, 150, (1, 5)), (1, 144, (1, 9)), (1, 128, (0, 4)), (2, 400, (1, 7)), (2, 304, (1, 5)), (2, 280, (1, 9))]]
+    # fp32-operand mode: form 2 = the fp32-chain kernel, "groups" = wavefronts per workgroup (4 up to one wavefront per SIMD, 8 beyond)
+    cases += [(_lib.PREC_F32, 2, 128, (2, 4)), (_lib.PREC_F32, 2, 150, (2, 8)), (_lib.PREC_F32, 1, 64, (2, 4)), (_lib.PREC_F32, 1, 400, (2, 8))]
+    for prec, cus, n, want in cases:
         A = rng.random((n, 40))
         _lib.debug_set_cus(cus)
         try:
-            h = nnlm_amd.Handle(0, _lib.PREC_F32)
+            h = nnlm_amd.Handle(0, prec)
         finally:
             _lib.debug_set_cus(0)
         with h:
@@ -97,8 +104,10 @@ def test_launch_policy_picks_the_cheapest_form(monkeypatch):
             assert (int(h.get_info("sweep_form_w")), int(h.get_info("sweep_groups_w"))) == want, (cus, n)
 
 
-def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd():
-    """the persistent form for any group count.  40000 columns (2500 groups of 16 on 1024 SIMDs: G = 10, 125 sweeps of
+@pytest.mark.parametrize("prec,form", [(_lib.PREC_F64, 1), (_lib.PREC_F32, 2)])
+def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd(prec, form):
+    """(fp32-operand mode: 20000 columns are one round of 157 eight-wavefront workgroups, 40000 two rounds of the 256 CUs.)
+    VERDICT r4 item 6: the persistent form for any group count.  40000 columns (2500 groups of 16 on 1024 SIMDs: G = 10, 125 sweeps of
     work per wavefront) must not cost more than 1.25 x per unit of work what 20000 columns cost (1250 groups: G = 5, 63 sweeps) -- the
     plain form took three whole rounds of wavefronts for 2.44 rounds of work there."""
     rng = np.random.default_rng(11)
@@ -106,7 +115,7 @@ def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd():
     per_col = {}
     for n in (20000, 40000):
         A = rng.random((n, m))
-        with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
+        with nnlm_amd.Handle(0, prec) as h:
             h.set_matrix(A)
             h.set_factors(k, 0.01 * rng.random((n, k)), 0.01 * rng.random((k, m)))
             for _ in range(3):
@@ -119,7 +128,7 @@ def test_sweep_time_scales_with_the_work_beyond_two_wavefronts_per_simd():
             h.sync()
             ms, cnt = h.profile_get("sweep_w")
             h.profile_enable(False)
-            assert cnt == 5 and int(h.get_info("sweep_form_w")) == 1
+            assert cnt == 5 and int(h.get_info("sweep_form_w")) == form
             per_col[n] = ms / cnt / n
             print(f"sweep_w at {n} columns: {ms / cnt:.4f} ms, G = {int(h.get_info('sweep_groups_w'))}")
     assert per_col[40000] <= 1.25 * per_col[20000], per_col
@@ -145,7 +154,7 @@ def test_forty_thousand_columns_on_the_real_device_match_the_oracle(pname, prec,
             W, _ = h.get_factors()
             sw = h.take_sweeps()
             if int(h.get_info("cus")) == 256:
-                assert int(h.get_info("sweep_form_w")) == want_form, (n, h.get_info("sweep_groups_w"))
+                assert int(h.get_info("sweep_form_w")) == (want_form if pname == "f64" else 2), (n, h.get_info("sweep_groups_w"))
         # the W half-step is update(Wt, H, A^T) (src/nnmf.cpp:131): Wt k x n solved, H the fixed factor, contraction over the m columns of A
         Wt, sweeps = ref.update(W0.T.copy(), H0, np.ascontiguousarray(A.T), None, reg, 50, 1e-9, 1)
         assert relF(W, Wt.T) < tol, (n, relF(W, Wt.T))
