@@ -41,8 +41,9 @@
 #include "k_sweep.h"
 #include "k_sweep_q.h"
 
-// accumulators whose A operands stay in registers (masked launches carry the mask words and one more code path: one fewer, no spills in the loop)
-#define SWEEPF_RES(has_mask) ((has_mask) ? 1 : 2)
+// accumulators whose A operands stay in registers: what 512 registers per lane (four wavefronts per workgroup, one per SIMD) or 256
+// (eight, two per SIMD) hold without a spill; masked launches carry the mask words and one more code path -- one fewer
+#define SWEEPF_RES(has_mask, nw) (((nw) == 8 ? 1 : 2) - ((has_mask) ? 1 : 0))
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -179,7 +180,7 @@ template <int NT, int NB, bool HAS_MASK, int NW>
 __device__ __forceinline__ void sweepf16_body(const SweepArgs &a, unsigned char *smem)
 {
     constexpr int KP = 16 * NT, NA = NT, GP = KP + 1, XS = KP + 2, COLS = 16 * NW, THREADS = 64 * NW;
-    constexpr int RES = SWEEPF_RES(HAS_MASK) < NA ? SWEEPF_RES(HAS_MASK) : NA;
+    constexpr int RES = SWEEPF_RES(HAS_MASK, NW) < NA ? SWEEPF_RES(HAS_MASK, NW) : NA;
     static_assert(NB <= 4 * NT && NB > 4 * (NT - 1) && NB >= 1, "NB = ceil(k / 4)");
     double *xl = (double *)smem;          // [COLS][XS]: x[column][coordinate], final values -- AFTER the prologue, in the place of
     double *gl = (double *)smem;          // [KP][GP]: G'
@@ -278,7 +279,7 @@ __device__ __forceinline__ void sweepf16_body(const SweepArgs &a, unsigned char 
     for (int g = 0; g < 4; g++) nsel[g] = (g4 == g) ? -1.0f : 0.0f;
     __syncthreads(); // operand image complete; G' is not read beyond this point: its place becomes the x image
     const u32x4 *opv = opl + lane;
-    u32x4 Ares[RES][NB]; // the operands of the first RES accumulators stay in registers, the others are fetched one step ahead
+    u32x4 Ares[RES ? RES : 1][NB]; // the operands of the first RES accumulators stay in registers, the others are fetched one step ahead
 #pragma unroll
     for (int T = 0; T < RES; T++)
 #pragma unroll
