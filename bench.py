@@ -44,6 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: the copy rate measured on the part (what a streaming kernel can reach)
 FP64_PEAK_TF = 78.6        # fp64 vector = matrix peak
 FP16_MFMA_PEAK_TF = 2500.0 # v_mfma_f32_16x16x32_f16 / bf16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 # KL solvers: 3 plain + 1 transcendental fp32 instruction per element and coordinate = 14.9 cycles per 64 elements per SIMD
@@ -164,12 +165,21 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
                 # (both modes since round 3: <.., STRICT = false / true>; round 4: between one and two 16-column wavefronts per SIMD -- 1024 SIMDs --
                 #  the launch takes the persistent form sweep_scd_qw_kernel: 5 .. 7 column groups per CU shared by the wrap-around rule)
                 # (which form the launch took is the library's decision -- device CU count, LDS limit: nnlm_get_info, recorded by the caller)
-                sweep_kernel = "sweep_scd_qw_kernel" if (sweep_forms or {}).get(nm) == 1 else "sweep_scd_q_kernel"
+                form = (sweep_forms or {}).get(nm)
+                sweep_kernel = {1: "sweep_scd_qw_kernel", 2: "sweep_scd_f_kernel"}.get(form, "sweep_scd_q_kernel")
                 knm = ("na_gram_f16_kernel + colsolve_fast_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
                         "flops = inner*cols*k*(2k+8); a SIMD runs one 16-column wavefront at full speed, so the floor of a launch is "
                         "max(inner, ceil(groups per CU * inner / 4)) sweeps of ~2.16 us")
+                if form == 2 and not cfg["na"]:
+                    # round 6, fp32-operand mode: fp32 chain state, rank-4 updates as three-piece bf16 products on v_mfma_f32_16x16x32_bf16.
+                    # Bound: instruction issue of ONE wavefront per SIMD (6.5 cycles per instruction, ~34 per block of 4 coordinates and
+                    # 16 columns: scripts/exp/issue_exp.hip, profiles/r06_issue_exp.log) -- reported against the fp32 vector/matrix peak for scale
+                    pk = 157.3
+                    note = ("fp32 chain (k_sweep_f.h): ~34 instructions per block of 4 coordinates x 16 columns at one instruction per 6.5 cycles "
+                            "from a lone wavefront (240 cycles per block at 2.4 GHz in isolation, ~300 at the ~1.9 GHz the clocks sit at behind the "
+                            "A-streaming kernels); flops = inner*cols*k*(2k+8) against the 157.3 TF fp32 peak, for scale only")
                 if cfg["na"]:
                     # + the per-column Grams over the complement rows, 2 k^2 flops per missing entry.  F32 mode: they run on the fp16 matrix
                     # cores as three split-fp16 products (a third of the dense fp16 peak per algorithmic flop); strict mode: fp64 MFMA.
@@ -199,7 +209,7 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
                     classes[nm] = dict(bound="valu", kernel=f"{nm} (kl_reg64_kernel)", work=el, peak=KL64_PEAK_GELEM, unit="Gelem/s", scale=1e9, pmc=None,
                                        note="fp64 VALU: ~12 fp64 instructions (correctly rounded quotient) per element and coordinate at 16 lanes per cycle per SIMD")
     if kern["errors"]["ms_per_launch"] and "errors" not in classes:
-        classes["errors"] = dict(bound="hbm", kernel="errors (errors_f32_kernel / errors_kernel<double> / reduction of the fused sums)", work=n * m * s / world,
+        classes["errors"] = dict(bound="hbm", kernel="errors (errors_f32_kernel / errors64_kernel: a separate pass over A)", work=n * m * s / world,
                                  peak=HBM_PEAK_GBS, unit="GB/s", scale=1e9, pmc=None)
 
     def block(nm):
@@ -209,6 +219,9 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
         traffic, src = (pmc_traffic(c["pmc"], config_id, s == 8) if (c["pmc"] and world == 1) else (None, None))
         b = dict(bound=c["bound"], kernel=c["kernel"], achieved=ach, peak=c["peak"], unit=c["unit"], frac=ach / c["peak"], traffic=traffic,
                  traffic_source=src, work_per_launch=c["work"], ms_per_launch=ms_l, share_of_kernel_time=None)
+        if c["bound"] == "hbm":  # next to the 8 TB/s pin rate: the copy rate the microarchitecture guide measured on this part
+            b["frac_of_achievable"] = ach / HBM_ACHIEVABLE_GBS
+            b["achievable"] = HBM_ACHIEVABLE_GBS
         if "note" in c:
             b["note"] = c["note"]
         return b
@@ -242,8 +255,10 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
     return roofline, secondary, all_blocks, shares
 
 
-SCOPES = ("xprod_h", "xprod_w", "xprod_w_err", "gram", "sweep_h", "sweep_w", "errors", "allgather", "allreduce", "unpack")
-# (allgather / allreduce: the RCCL collective of a sharded half-step between two HIP events on the stream it is enqueued on -- includes
+SCOPES = ("xprod_h", "xprod_w", "xprod_w_err", "gram", "sweep_h", "sweep_w", "errors", "err_reduce", "allgather", "allreduce", "unpack")
+# (errors: a separate pass over A -- errors_f32_kernel / errors64_kernel; err_reduce: the 5 us reduction of the partial sums the fused cross
+#  product xprod16_err_kernel left behind, no HBM work of its own -- not priced against a roofline;
+#  allgather / allreduce: the RCCL collective of a sharded half-step between two HIP events on the stream it is enqueued on -- includes
 #  the wait for the slowest rank; unpack: shard_unpack_kernel + the sum of the ranks' Gram partial sums)
 
 
@@ -256,7 +271,8 @@ def profile_scopes(h):
 
 
 def sweep_forms_of(h):
-    """{"sweep_w": 0 | 1 | -1, "sweep_h": ...}: form of the handle's last SCD sweep launches (0 plain, 1 persistent; nnlm_get_info)."""
+    """{"sweep_w": 0 | 1 | 2 | -1, "sweep_h": ...}: form of the handle's last SCD sweep launches (0 plain fp64 chain, 1 persistent fp64 chain,
+    2 fp32 chain -- the fp32-operand mode since round 6; nnlm_get_info)."""
     return {"sweep_w": int(h.get_info("sweep_form_w")), "sweep_h": int(h.get_info("sweep_form_h"))}
 
 
@@ -340,6 +356,31 @@ def self_launch(n_ranks):
     return rc
 
 
+def step_block(cfg, n, m, k, s, trace, ms_step):
+    """The whole step against SURVEY section 8d's per-iteration figures.  s = bytes per stored element of A (4: fp32-operand mode, 8: strict)."""
+    inner, method = cfg["inner"], cfg["method"]
+    b_it = 2.0 * n * m * s + 4.0 * k * (n + m) * s + (n * m * s / trace if trace > 0 else 0.0)
+    hbm_ms = b_it / (HBM_PEAK_GBS * 1e9) * 1e3
+    if method < 3 and not cfg["na"]:   # configs 2 / 4: two A-streaming skinny GEMMs per iteration
+        f_it = 4.0 * n * m * k + 4.0 * k * k * (n + m)
+        ceil_ms = max(hbm_ms, f_it / ((157.3e12 if s == 4 else 78.6e12)) * 1e3)
+        note = "SURVEY 8d: B_it = 2nm s + 4k(n+m)s (+ nm s per trace iteration); ceiling = max(B_it / 8 TB/s, F_it / MFMA peak)"
+    elif method >= 3:                  # config 3: KL solvers, sequential in k -- VALU / transcendental rate, not HBM
+        f_it = 2.0 * 7.0 * n * m * k * inner
+        ceil_ms = max(hbm_ms, f_it / ((157.3e12 if s == 4 else 78.6e12)) * 1e3)
+        note = ("SURVEY 8d: VALU work 2 x 7 n m k inner flop-equivalents per iteration (incl. 2 n m k inner divides) against the "
+                + ("157.3 TF fp32" if s == 4 else "78.6 TF fp64") + " vector peak; bytes as config 2")
+    else:                              # config 5: per-column Grams over the complement rows on the matrix cores
+        nmiss = n * m // 10
+        f_it = 2.0 * 2.0 * k * k * min(nmiss, n * m - nmiss)
+        pk = (FP16_MFMA_PEAK_TF / 3.0 if s == 4 else FP64_PEAK_TF) * 1e12
+        ceil_ms = max(hbm_ms, f_it / pk * 1e3)
+        note = ("SURVEY 8d: Gram flops 2 k^2 min(nnz, nm - nnz) per half-step on "
+                + ("the fp16 matrix cores as three split products (2.5 PF / 3)" if s == 4 else "the fp64 matrix cores (78.6 TF)") + "; bytes as config 2")
+    return dict(bytes_per_iteration=b_it, flops_per_iteration=f_it, hbm_frac=b_it / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, ceiling_ms=ceil_ms,
+                ceiling_it_per_s=1e3 / ceil_ms, frac_of_ceiling=ceil_ms / ms_step, note=note)
+
+
 def other_config(config_id, precision, n, m, k, local_rank, steps, warmup):
     """A short run of another configuration on the same device (N = 1): ms per step, dominant kernel class, its fraction."""
     import nnlm_amd
@@ -367,6 +408,7 @@ def other_config(config_id, precision, n, m, k, local_rank, steps, warmup):
     roof, _, blocks, shares = analyse(cfg, config_id, kern, n, m, k, 8 if precision == "f64" else 4, 1, forms)
     return dict(workload=cfg["name"].format(n=n, m=m, k=k), dtype=DTYPE_NAMES[precision], steps=steps, warmup=warmup, trace=trace,
                 ms_per_step=1e3 * dt / steps, iterations_per_s=steps / dt, final_mse=float(r["mse_error"][-1]),
+                step=step_block(cfg, n, m, k, 8 if precision == "f64" else 4, trace, 1e3 * dt / steps),
                 dominant=dict(kernel=roof["kernel"], bound=roof["bound"], frac=roof["frac"], ms_per_launch=roof["ms_per_launch"],
                               share_of_kernel_time=roof["share_of_kernel_time"]) if roof else None,
                 kernels_ms_per_launch={kk: v["ms_per_launch"] for kk, v in kern.items() if v["ms_per_launch"]},
@@ -545,14 +587,8 @@ def main():
     inner, method = cfg["inner"], cfg["method"]
     roofline, secondary, all_blocks, shares = analyse(cfg, args.config, kern, n, m, k, s, world, main_forms)
 
-    # whole step against SURVEY 8d's per-iteration figures (config 2): bytes A twice + factors, +A once on trace iterations
     ms_step = 1e3 * elapsed / args.steps
-    b_it = 2.0 * n * m * s + 4.0 * k * (n + m) * s + (n * m * s / trace if trace > 0 else 0.0)
-    f_it = 4.0 * n * m * k + 4.0 * k * k * (n + m)
-    ceil_ms = max(b_it / (HBM_PEAK_GBS * 1e9), f_it / 157.3e12) * 1e3 if s == 4 else max(b_it / (HBM_PEAK_GBS * 1e9), f_it / 78.6e12) * 1e3
-    step = dict(bytes_per_iteration=b_it, hbm_frac=b_it / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, ceiling_it_per_s=1e3 / ceil_ms,
-                frac_of_ceiling=(args.steps / elapsed) / (1e3 / ceil_ms),
-                note="SURVEY 8d: B_it = 2nm s + 4k(n+m)s (+ nm s per trace iteration); ceiling = max(B_it / 8 TB/s, F_it / MFMA peak)") if method < 3 and not cfg["na"] else None
+    step = step_block(cfg, n, m, k, s, trace, ms_step)
 
     cpu = mse_check = None
     if args.cpu_iters > 0 and world == 1 and not force_comm:  # the CPU baseline is timed on rank 0 at N=1 only
@@ -611,8 +647,8 @@ def main():
         "step": step,
         "cpu_baseline": cpu,
         "mse_check": mse_check,
-        "phases_ms": dict(phases_ms, note="HIP-event time per step of each phase in the profiled replay, max over ranks; 'gram' = Gram + split copy + "
-                                           "sweep operand image; N > 1: 'allgather' / 'allreduce' = the RCCL call between two events on its stream "
+        "phases_ms": dict(phases_ms, note="HIP-event time per step of each phase in the profiled replay, max over ranks; 'gram' = Gram fold + split copy; "
+                                           "'err_reduce' = reduction of the fused error sums; N > 1: 'allgather' / 'allreduce' = the RCCL call between two events on its stream "
                                            "(includes waiting for the slowest rank), 'unpack' = scatter of the gathered slabs (+ split copy + Gram sum)"),
         "kernels": kern,
         "kernel_time_share": shares,

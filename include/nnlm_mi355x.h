@@ -150,7 +150,8 @@ int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double pen[6]);
 int nnlm_sync(nnlm_handle *h);
 
 /* Per-kernel device timing (HIP events on the handle's stream) for bench.py's roofline block.
- * names: "xprod_h" (A-streaming W^T A), "xprod_w" (A H^T), "gram", "sweep_h", "sweep_w", "errors". */
+ * names: "xprod_h" (A-streaming W^T A), "xprod_w" (A H^T), "xprod_w_err" (the same with the fused error sums), "gram", "sweep_h",
+ * "sweep_w", "errors" (a separate pass over A), "err_reduce" (reduction of the fused error sums), "allgather", "allreduce", "unpack". */
 int nnlm_profile_enable(nnlm_handle *h, int on);
 int nnlm_profile_get(nnlm_handle *h, const char *name, double *total_ms, long long *launches);
 int nnlm_profile_reset(nnlm_handle *h);
@@ -204,7 +205,8 @@ int nnlm_debug_set_cus(int cus);
 int nnlm_debug_alloc_limit(size_t bytes);
 /* Facts about the handle's last launches, for bench.py's kernel attribution: key = "cus" (compute units the launch policy
  * counts), "sweep_form_w" / "sweep_form_h" (SCD sweep of the last W / H half-step: 0 plain sweep_scd_q_kernel, 1 persistent
- * sweep_scd_qw_kernel, -1 none yet), "sweep_groups_w" / "sweep_groups_h" (column groups per workgroup of that launch). */
+ * sweep_scd_qw_kernel -- both strict fp64 --, 2 sweep_scd_f_kernel (fp32-operand mode), -1 none yet), "sweep_groups_w" /
+ * "sweep_groups_h" (column groups -- form 2: wavefronts -- per workgroup of that launch). */
 int nnlm_get_info(nnlm_handle *h, const char *key, double *value);
 
 #ifdef __cplusplus

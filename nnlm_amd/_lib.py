@@ -355,7 +355,7 @@ class Handle:
         self._ck(self._lib.nnlm_comm_set_form(self._h, FORMS[form] if isinstance(form, str) else int(form)))
 
     def get_info(self, key):
-        """cus, sweep_form_w / sweep_form_h (0 plain, 1 persistent, -1 none yet), sweep_groups_w / sweep_groups_h."""
+        """cus, sweep_form_w / sweep_form_h (0 plain, 1 persistent -- strict fp64 --, 2 fp32 chain, -1 none yet), sweep_groups_w / sweep_groups_h."""
         v = C.c_double(0)
         self._ck(self._lib.nnlm_get_info(self._h, key.encode(), C.byref(v)))
         return v.value

@@ -38,11 +38,13 @@
 
 static thread_local std::string g_last_error;
 
-enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_XPROD_W_ERR, P_ALLGATHER, P_ALLREDUCE, P_UNPACK, P_COUNT };
+enum ProfId { P_XPROD_H = 0, P_XPROD_W, P_GRAM, P_SWEEP_H, P_SWEEP_W, P_ERRORS, P_XPROD_W_ERR, P_ALLGATHER, P_ALLREDUCE, P_UNPACK, P_ERR_REDUCE, P_COUNT };
 // ("xprod_w_err": W half-step cross products that also evaluate the error sums -- the fused launches have a scope of their own;
 //  "allgather" / "allreduce": the RCCL collective of a sharded half-step between two events on the stream it is enqueued on;
 //  "unpack": shard_unpack_kernel + the sum of the ranks' Gram partial sums behind it)
-static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors", "xprod_w_err", "allgather", "allreduce", "unpack"};
+//  "errors": a separate pass over A (errors_f32_kernel / errors64_kernel + its reduction); "err_reduce": the reduction of the partial sums the
+//  fused cross product left behind -- 5 us, no HBM work: it must not be priced as a pass over A
+static const char *kProfNames[P_COUNT] = {"xprod_h", "xprod_w", "gram", "sweep_h", "sweep_w", "errors", "xprod_w_err", "allgather", "allreduce", "unpack", "err_reduce"};
 
 struct ProfRec {
     int id;
@@ -2455,8 +2457,8 @@ static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int f
 {
     const int k4 = round_up_i(h->k, 4);
     if (fused_nb > 0) {
-        ProfScope ps(h, P_ERRORS, st);
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_xdone, 0));
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_xdone, 0)); // (ahead of the scope: the wait for the fused cross product is not this phase's time)
+        ProfScope ps(h, P_ERR_REDUCE, st);
         reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, (size_t)fused_nb, 2, h->scal);
     } else {
         ProfScope ps(h, P_ERRORS, st);
