@@ -143,6 +143,10 @@ struct nnlm_handle {
     bool fuse_err = false;       // request: the next W half-step's cross product also evaluates the error sums of (W, H) now current
     int cus_device = 0;          // the device's CU count (cus may be the test hook's)
     int fused_nb = 0;            // answer: number of (sum of squares, KL) pairs it left in `partials` (0 = not fused)
+    // multi-GPU: the error block of a trace iteration is enqueued from INSIDE the speculative W half-step, right behind its cross product:
+    // its all-reduces (two sums, one sweep counter) must be issued ahead of that half-step's all-gather -- RCCL runs a communicator's
+    // collectives in issue order, and behind the all-gather the host would learn the stopping decision only when the whole half-step is done
+    bool err_hook = false, err_need_pen = true, err_launched = false;
     unsigned *err_zero_word = nullptr; // the fused kernel clears this word (max|x| of the sweep that follows it; see factor16_fold_err_kernel)
     unsigned long long *sweeps_tmp = nullptr; // device scratch for the all-reduced sweep counter
 
@@ -1085,12 +1089,13 @@ static void launch_xprod16_err_m(nnlm_handle *h, const HalfPlan &p)
         xprod16_err_kernel<NKQ, true><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
                                                                                (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
                                                                                h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word, h->missT,
-                                                                               h->mpad / 32);
+                                                                               h->mpad / 32, p.col_off);
     } else {
         set_dyn_lds((const void *)xprod16_err_kernel<NKQ, false>, lds, "xprod16_err_kernel");
         xprod16_err_kernel<NKQ, false><<<grid, XPROD_THREADS, lds, h->stream>>>(h->A16T, h->mpad, h->Y16, h->mpad, h->H16c, h->W16c, h->Cx, h->npad,
                                                                                 (size_t)16 * NKQ * h->npad, p.stage_begin, p.stage_end, p.sps, h->scal_exp,
-                                                                                h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word);
+                                                                                h->scal_exp + 2, h->n, h->m, h->partials, h->err_zero_word, nullptr, 0,
+                                                                                p.col_off);
     }
     h->err_zero_word = nullptr;
     h->fused_nb = p.tiles_x * p.S;
@@ -1917,6 +1922,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     return NNLM_OK;
 }
 
+static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb, bool need_pen);
 // speculative (W half-step only): the result goes to the alternate W buffers and the alternate sweep counter and is
 // NOT made current; the caller accepts it later with swap_w() / sw_active ^= 1, or simply drops it.
 static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned inner_max_iter, double inner_rel_tol, int method,
@@ -2120,6 +2126,19 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         }
     }
     if (speculative) HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream)); // the error block starts once A is no longer streamed
+    if (speculative && h->err_hook) { // (multi-GPU trace iteration: see err_hook)
+        h->err_hook = false;
+        int fnb = h->fused_nb;
+        if (h->fuse_err && fnb == 0) { // a rank without columns launched no fused cross product: it contributes zeros to the two sums
+            HIPCHK(h, hipMemsetAsync(h->partials, 0, 2 * sizeof(double), h->stream));
+            HIPCHK(h, hipEventRecord(h->ev_xdone, h->stream));
+            fnb = 1;
+        }
+        const int rce = errors_launch(h, h->stream_e, true, fnb, h->err_need_pen);
+        if (rce != NNLM_OK) return rce;
+        h->fused_nb = 0;
+        h->err_launched = true;
+    }
     // (multi-GPU) fold the split-K slabs into the contiguous [G | C] buffer; ONE all-reduce sums it over ranks
     if (h->sharded && !colshard) {
         const int ld = (which == 1) ? h->mpad : h->npad;
@@ -2453,13 +2472,17 @@ extern "C" int nnlm_sync(nnlm_handle *h)
 // fused_nb > 0: the two sums were left as fused_nb partial pairs in h->partials by the cross product of the speculative
 // W half-step (xprod16_err_kernel); only their reduction, the penalties and the counters remain.
 // need_pen: the six penalty sums of add_penalty() -- nnlm_run skips them when alpha = beta = 0 (penalties() then uses none of them)
-static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb = 0, bool need_pen = true)
+static int errors_launch(nnlm_handle *h, hipStream_t st, bool with_sweeps, int fused_nb, bool need_pen)
 {
     const int k4 = round_up_i(h->k, 4);
     if (fused_nb > 0) {
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_xdone, 0)); // (ahead of the scope: the wait for the fused cross product is not this phase's time)
         ProfScope ps(h, P_ERR_REDUCE, st);
         reduce_partials_kernel<<<1, REDUCE_THREADS, 0, st>>>(h->partials, (size_t)fused_nb, 2, h->scal);
+        if (h->sharded && h->comm) { // every rank's fused cross product covered ITS part of A: sum the two sums
+            ncclResult_t r = g_rccl.AllReduce(h->scal, h->scal, 2, ncclDouble, ncclSum, (ncclComm_t)h->comm, st);
+            if (r != ncclSuccess) return fail(h, NNLM_ERR_COMM, "ncclAllReduce (fused error sums) failed");
+        }
     } else {
         ProfScope ps(h, P_ERRORS, st);
         const uint32_t *miss = h->any_missing ? h->miss : nullptr;
@@ -2567,7 +2590,7 @@ extern "C" int nnlm_errors(nnlm_handle *h, double *mse, double *mkl_var, double 
 {
     if (!h || !h->A || !h->W64) return fail(h, NNLM_ERR_ARG, "nnlm_errors: matrix and factors must be set first");
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = errors_launch(h, h->stream, false);
+    int rc = errors_launch(h, h->stream, false, 0, true);
     if (rc != NNLM_OK) return rc;
     return errors_collect(h, mse, mkl_var, pen, nullptr);
 }
@@ -2839,6 +2862,7 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         {
             if (!pending) return;
             h->sg_which = h->sg_other = -1;
+            h->gshard_for = h->upk_max_for = h->y16_for = -1; // (multi-GPU: what the dropped half-step's unpack left behind describes a W that is not current)
             h->fuse_err = false;
             h->fused_nb = 0;
             hipMemsetAsync(h->sweeps + (h->sw_active ^ 1), 0, sizeof(unsigned long long), h->stream);
@@ -2863,7 +2887,12 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
         if (i % trace == 0) {                                                   // src/nnmf.cpp:135-160
             HIPCHK(h, hipEventRecord(h->ev_hdone, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_hdone, 0));
-            if (i + 1 < max_iter && !h->sharded && method < 3) {
+            // (multi-GPU: the dense square-loss flows of the fp32-operand mode at rank <= 64 -- every rank's speculative cross product
+            //  covers its own part of A, so the fused sums are a partition of the error sums; the accept / drop decision is a function
+            //  of the all-reduced sums and therefore the same on every rank)
+            const bool spec_sharded = h->sharded && h->x16 && !generic_rank(h) && !h->any_missing;
+            h->err_launched = false;
+            if (i + 1 < max_iter && (!h->sharded || spec_sharded) && method < 3) {
                 // speculative W half-step of iteration i+1 (not made current: h->W64 still is W_i below).  The error block
                 // (one more pass over A) starts together with it: since the cross product became HBM bound (k_xprod16.h) the
                 // two streams of A share the bandwidth, but the error block is then finished before the latency-bound sweep
@@ -2873,8 +2902,11 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 // (xprod16_err_kernel) and no separate pass over A is needed.
                 h->fuse_err = h->x16 && !generic_rank(h);
                 h->fused_nb = 0;
+                h->err_hook = h->sharded;
+                h->err_need_pen = need_pen;
                 rc = half_step(h, 0, alpha, inner_max_iter, inner_rel_tol, method, false, true);
                 h->fuse_err = false;
+                h->err_hook = false;
                 if (rc != NNLM_OK) {
                     g_last_error = h->err;
                     return rc;
@@ -2890,7 +2922,8 @@ extern "C" int nnlm_run(nnlm_handle *h, const double alpha[3], const double beta
                 if (h->prec == NNLM_PREC_F64 && !h->fused_nb) HIPCHK(h, hipStreamWaitEvent(h->stream_e, h->ev_xdone, 0));
             } else
                 h->fused_nb = 0;
-            CHK(errors_launch(h, h->stream_e, true, h->fused_nb, need_pen)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            if (!h->err_launched) CHK(errors_launch(h, h->stream_e, true, h->fused_nb, need_pen)); // reads W_i, H_i and the active sweep counter (then zeroes it)
+            h->err_launched = false;
             h->fused_nb = 0;
             // H (and the fp32 copy the error kernel reads) must not be rewritten before the error block is done
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_err, 0));

@@ -180,8 +180,9 @@ __global__ __launch_bounds__(256) void errors_kernel(const T *__restrict__ A, in
 #define ERR64_UNROLL 2
 #endif
 #define ERR64_HR 8 // 16-byte pieces of a slice per lane: ranks up to 64
-// (Ablations of errors64_kernel -- no sums, no matrix phase, no A loads, no barrier / slice loads: scripts/exp/csrc_r5/k_errors.h with
-// scripts/exp/err64_exp.hip.  The product kernel carries no switch.)
+#ifndef ERR64_EXP
+#define ERR64_EXP 0 // ablation switches of scripts/exp/err64_exp.hip only: 1 no sums, 2 no matrix phase, 4 no A loads
+#endif
 __host__ __device__ static inline int errors64_lds_bytes(int k4) { return 3 * k4 * 512; }
 
 template <bool MASKED>
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    av[a][b][r] = A[(size_t)(jt * ERR_TILE + jb + 16 * b + lg + 4 * r) * lda + i0 + ib + 16 * a + l15];
+                    av[a][b][r] = (ERR64_EXP & 4) ? 0.5 : A[(size_t)(jt * ERR_TILE + jb + 16 * b + lg + 4 * r) * lda + i0 + ib + 16 * a + l15];
     };
 
     __shared__ f64x2 ltab[64]; // nnlm_log_tab
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
     auto tile = [&](int jt, int buf, double (&av)[2][2][4], uint32_t (&mw)[2][4], double (&avn)[2][2][4], uint32_t (&mwn)[2][4]) {
         const int jn = (jt + 1 < jt_end) ? jt + 1 : jt; // (unconditional requests: a conditional load is a phi, and the phi a copy behind a full wait)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(ERR64_EXP & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        slice_load(H64, ldh, jn * ERR_TILE, hr);
+        if (!(ERR64_EXP & 8)) slice_load(H64, ldh, jn * ERR_TILE, hr);
         const unsigned char *hrow = Hs + buf * slice_bytes + lg * 512;
         f64x4 acc[2][2];
 #pragma unroll
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
 #define E64_READ(w0_, w1_, h0_, h1_, step)                                                                                              \
     {                                                                                                                                 \
         const unsigned o_ = (unsigned)(step) * 2048u;                                                                                 \
+        if (!(ERR64_EXP & 16) || (step) == 0)                                                                                         \
         asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"                          \
                      : "=&v"(w0_), "=&v"(w1_), "=&v"(h0_), "=&v"(h1_)                                                                   \
                      : "v"(aw0 + o_), "v"(aw1 + o_), "v"(ah0 + o_), "v"(ah1 + o_)                                                      \
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(h1_, w1_, acc[1][1], 0, 0, 0);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                                           \
     }
-        const int ns = k4 >> 2; // k steps of 4
+        const int ns = ((ERR64_EXP & 2) ? 4 : k4) >> 2; // k steps of 4
         const int nl = ns - 1;
         double rw0, rw1, rh0, rh1;
         E64_READ(pw0, pw1, ph0, ph1, 0);
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
 #undef E64_MMA
         if constexpr (!HAS_MISS) tile_a(jn, avn, mwn); // (with missing entries: ONE register set, requested behind the sums -- see below)
         const bool masked = HAS_MISS || iedge || ((jt + 1) * ERR_TILE > m); // block uniform
-        if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl, ltab);
+        if (ERR64_EXP & 1) s2 += acc[0][0][0] + acc[1][1][3] + acc[0][1][1] + acc[1][0][2] + av[0][0][0] + av[1][1][3];
+        else if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl, ltab);
         else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl, ltab);
         // (the masked sums + the mask words + two sets of A spilled 136 .. 928 bytes: with missing entries the next tile is requested
         //  into the SAME set once this tile's sums are done; the next matrix phase covers most of its latency)

@@ -573,8 +573,11 @@ __device__ static inline float kl_wave_total(float v)
 #ifndef KLT_PIN
 #define KLT_PIN 1 // 1: keep every chunk's arithmetic between its own row request and the next one (see pass A)
 #endif
-// (Ablations of kl_tile_kernel -- no barrier / scalar part, no row requests: scripts/exp/csrc_r5/k_kl.h with scripts/exp/klt_exp.hip.  The
-// product kernel carries no switch.)
+#ifndef KLT_EXP
+#define KLT_EXP 0 // ablations (timing experiments only; results are wrong): 1 no barrier / scalar part, 2 no row requests.  (Rounds 2-4 also had
+                  // 4 "no pass B" and 8 "no pass A": without pass B the state never changes and the compiler hoists every reciprocal out of the
+                  // coordinate loop, without pass A nothing reads the state and pass B is dead code -- they did not measure what they said.)
+#endif
 // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the vector-memory queue, i.e. wait for the
 // row prefetch (LDS-DMA) at every coordinate step.  Each wavefront reads back only LDS slots its own LDS-DMA wrote, after its
 // own s_waitcnt vmcnt, so the barrier has nothing to order there.
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)sp);
         const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
         // (only slots of the LAST piece can lie beyond the end of the arrays: L4 >= 512 (EPT4 - 1) + 64 wave whenever that piece exists)
+        if ((KLT_EXP & 2) && q > 1) return;
         if (e + 1 < EPT4 || e * NT + wave * 64 + lane < L4)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(su), "s"(du) : "memory");
     };
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
                     }
             }
             KLT_T(3);
-            KLT_BARRIER();
+            if (!(KLT_EXP & 1)) KLT_BARRIER();
             KLT_T(4);
             // pass B's first row elements are requested here, behind the reads of the wave totals and in front of the scalar part: they
             // arrive while it runs (KV & 4; otherwise in front of the pass itself)
@@ -852,7 +856,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
             constexpr int PD = ONEBUF ? KLT_PBD1 : ((EPT4 < PDW) ? EPT4 : PDW);
             f32x4 wb[PD + 1];
             float coef_l = 0.f;
-            {
+            if (KLT_EXP & 1) coef_l = 1e-12f * (acc[0][0][0] + acc[C - 1][NV - 1][3]);
+            else {
                 f32x4 rrv[NV][NW / 4]; // the wave totals of the lane's column (fp32, like the totals themselves)
 #pragma unroll
                 for (int v = 0; v < NV; v++)
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
               // the pass makes the compiler copy all state registers where the two paths meet)
                 // (two fused multiply-adds per chunk and column do not cover an LDS round trip: with the row element one chunk ahead, as
                 //  in pass A, the pass waited ~100 cycles per chunk -- 0.8-1.0 of a half-step's 2.3 ms at config 3; KLT_PBD chunks ahead)
-                if (!(KV & 4)) {
+                if (!(KV & 4) || (KLT_EXP & 1)) {
 #pragma unroll
                     for (int e = 0; e < PD; e++)
                         if (KLT_HAS(e)) wb[e] = wload(e);

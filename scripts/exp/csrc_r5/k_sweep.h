@@ -159,9 +159,10 @@ __device__ static inline void sweep_load_gram(double *Gp, f64x2 *Gd, const Sweep
     }
 }
 
-// (Ablations -- no AXPY FMAs, no LDS traffic in the loop, no rel-change test, chain cut: scripts/exp/csrc_r5/k_sweep.h with
-// scripts/exp/sweep_exp.hip.  The product kernel carries no switch.)
-template <int R, int L, int METHOD>
+// EXP: ablation switches for scripts/exp/sweep_exp.hip only (0 in the product): bit0 drop the AXPY FMAs, bit1 keep
+// re-using the first fetched row (no LDS traffic in the loop), bit2 drop the rel-change test, bit3 cut the dependent
+// chain (d does not depend on mu).
+template <int R, int L, int METHOD, int EXP = 0>
 __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
 {
     constexpr int CH = SWEEP_CH;
@@ -269,15 +270,16 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                     const bool owner = (sub == s);
                     if (METHOD == 1) {
                         // L is even or 1: the two row buffers alternate with the parity of s (static)
-                        GRow &cur = ((s & 1) == 0 || L == 1) ? rowA : rowB;
+                        GRow &cur = ((s & 1) == 0 || L == 1 || (EXP & 2)) ? rowA : rowB;
                         GRow &nxt = ((s & 1) == 0 || L == 1) ? rowB : rowA;
                         const double gownq = gown[(size_t)q * (L * R)];
                         int qn = q + 1;
                         qn = (qn >= k) ? 0 : qn; // after the last coordinate the next sweep starts at 0
-                        if (L > 1) fetch(nxt, qn);
+                        if (L > 1 && !(EXP & 2)) fetch(nxt, qn);
                         // vcur = this lane's mu for ITS coordinate of the block.  Every lane runs the chain on its own values;
                         // the DPP broadcast below picks the owner sub-lane's result, so no owner test sits on the chain, and
                         // tmp - x is exactly 0 when nothing changes, so neither does the reference's `tmp != Hj(k)` test.
+                        if (EXP & 8) vcur = vown;
                         const double q0 = vcur * cur.gd[1];
                         const double rr = __builtin_fma(-q0, cur.gd[0], vcur);
                         const double quo = __builtin_fma(rr, cur.gd[1], q0); // = mu / G[q][q], correctly rounded
@@ -287,17 +289,17 @@ __global__ __launch_bounds__(64) void sweep_ls_kernel(const SweepArgs a)
                                          : (s == 2) ? dpp_bcast<L, (L > 2 ? 2 : 0)>(dd) : dpp_bcast<L, (L > 3 ? 3 : 0)>(dd);
                         if (L > 1) vcur = __builtin_fma(d, gownq, vcur); // keeps the chain out of the indexed registers
 #pragma unroll
-                        for (int r2 = 0; r2 < R; r2 += 2) {
+                        for (int r2 = 0; r2 < ((EXP & 1) ? 2 : R); r2 += 2) {
                             v[r2 / CH][r2 % CH] = __builtin_fma(d, cur.g[r2 / 2][0], v[r2 / CH][r2 % CH]);
                             v[(r2 + 1) / CH][(r2 + 1) % CH] = __builtin_fma(d, cur.g[r2 / 2][1], v[(r2 + 1) / CH][(r2 + 1) % CH]);
                         }
                         // rel-change test of src/base_algorithms.cpp:29-32 without the division:
                         //   2|d| / (tmp + x + eps) > tol   <=>   2|d| > tol * (tmp + x + eps)
                         // (the rounded quotient's decision: the division is formed only where the two sides agree to ~2 ulp, common.h)
-                        const bool big = rel_change_exceeds(2 * fabs(dd), tmp + xown + NNLM_TINY, tol);
+                        const bool big = (EXP & 4) ? true : rel_change_exceeds(2 * fabs(dd), tmp + xown + NNLM_TINY, tol);
                         flag |= (owner && big) ? 1 : 0;
                         xnew = (free_q && owner) ? tmp : xnew;
-                        if (L == 1) fetch(rowA, qn);
+                        if (L == 1 && !(EXP & 2)) fetch(rowA, qn);
                     } else {
                         const f64x2 *gq = grow + (size_t)q * (L * R / 2);
                         double part = 0.0, part2 = 0.0;

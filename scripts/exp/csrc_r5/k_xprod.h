@@ -78,9 +78,9 @@ __device__ static inline int strided_count(int wave, int cnt) { return (wave < c
 // swizzle is applied to the per-lane GLOBAL source address (cdna_hip_programming.md rule 21).
 // Wave w owns image rows (columns j) [16w, 16w+16): one M-tile x NKQ N-tiles.
 // ------------------------------------------------------------------------------------------------
-// (Ablations of this kernel -- factor / A image loaded for the first two stages only, no MFMA phase, fragments from registers, every
-// wavefront issuing in front of its MFMA phase: scripts/exp/csrc_r5/k_xprod.h with scripts/exp/xprod_exp.hip / xprod64_exp.hip.  The product
-// kernel carries no switch.)
+// EXP: ablation switches for scripts/exp/xprod_exp.hip only (0 in the product): bit0 load the factor image only for the
+// first two stages, bit1 skip the MFMA phase, bit2 load the A image only for the first two stages, bit5 every wavefront issues its requests in
+// front of its MFMA phase (the form before round 5).
 typedef float xp_f32x2 __attribute__((ext_vector_type(2)));
 typedef double xp_f64x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct XpVec2;
@@ -92,7 +92,7 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 // KT > 0: the rank is 16*NKQ + (1..KT) -- the last KT (2 or 4) rows of the factor are NOT padded to a fourth 16-wide MFMA tile
 // (k = 50 would issue 64/50 = 28 % more MFMAs); their dot products run as KT*EPV plain FMAs per fragment in the shadow of
 // the MFMAs, on the A fragment the lane already holds, and are summed across the four lane groups in the epilogue.
-template <typename T, int NKQ, int KT = 0>
+template <typename T, int NKQ, int KT = 0, int EXP = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__restrict__ A, int lda,
                                                                  const T *__restrict__ Yop, int ldy,
                                                                  double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -138,11 +138,13 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     const unsigned long long baseA = xp_uniform64(A + (size_t)j0 * lda), baseY = xp_uniform64(Yop);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     auto issue = [&](int st, unsigned char *buf) {
-        const unsigned long long bA = (unsigned long long)st * XPROD_ROWB, bY = bA;
+        const unsigned long long bA = (unsigned long long)(((EXP & 4) && st > st0 + 1) ? st0 : st) * XPROD_ROWB;        // EXP: re-read a cached stage
+        const unsigned long long bY = (unsigned long long)(((EXP & 5) == 5 && st > st0 + 1) ? st0 : st) * XPROD_ROWB;
         const unsigned dst = lds0 + (unsigned)(buf - smem) + (unsigned)wave * 1024u;
 #pragma unroll
         for (int i = 0; i < XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES; i++)
             glds16_s(voffA, baseA + bA + (unsigned long long)i * 32ull * (unsigned long long)lda * sizeof(T), dst + (unsigned)i * 8192u);
+        if ((EXP & 1) && st > st0 + 1) return;
 #pragma unroll
         for (int i = 0; i < (YI + XPROD_WAVES - 1) / XPROD_WAVES; i++)
             if (wave + XPROD_WAVES * i < YI)
@@ -151,29 +153,41 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
     };
 
     // loads THIS wavefront issues per stage (A image: 32 instructions over 8 waves; factor image: KP/4 instructions)
-    const int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
+    int per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES + strided_count(wave, YI);
+    if (EXP & 1) per_stage = XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES;
     if (st0 < st1) issue(st0, smem);
     if (st0 + 1 < st1) issue(st0 + 1, smem + BUF);
     // fp64 (round 5): wavefronts 4..7 hand their requests of stage st + 2 to the memory pipeline BEHIND their MFMA phase, wavefronts 0..3
     // in front of it.  A wavefront sits in the issue queue until the pipeline takes its 5-6 KB (most of a stage's HBM time when all eight
     // ask at once) and issues no MFMA meanwhile; with the two wavefronts of a SIMD asking at different times one of them computes --
     // 0.392 -> 0.377 ms (H) / 0.399 -> 0.385 (W) at config 2 (scripts/exp/xprod64_exp.hip).  The split-fp16 kernel's MFMA phase is a
-    // quarter of this one's and gains nothing (measured: scripts/exp/csrc_r5/k_xprod16.h, EXP bit 3).  Same buffers, same counted waits: requests complete in issue
+    // quarter of this one's and gains nothing (k_xprod16.h, EXP bit 3).  Same buffers, same counted waits: requests complete in issue
     // order per wavefront, and stage st + 2's buffer is free from the barrier of stage st on.
-    const bool late = sizeof(T) == 8 && wave >= XPROD_WAVES / 2;
+    const bool late = sizeof(T) == 8 && !(EXP & (32 | 16)) && wave >= XPROD_WAVES / 2;
     int since_flush = 0;
     for (int st = st0; st < st1; ++st) {
         unsigned char *buf = smem + ((st - st0) % XPROD_NBUF) * BUF;
         // stage `st` has landed once at most the newer stage's loads are outstanding; the barrier then also tells
         // every wave that stage st-1 has been consumed, so its buffer may be refilled with stage st+2
-        wait_vmcnt((st + 1 < st1) ? per_stage : 0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (st + 2 < st1 && !late) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        if constexpr ((EXP & 16) == 0) {
+            wait_vmcnt((st + 1 < st1) ? per_stage : 0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + 2 < st1 && !late) issue(st + 2, smem + ((st + 2 - st0) % XPROD_NBUF) * BUF);
+        }
+        if (EXP & 2) continue;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int phys = ((lg + 4 * kk) ^ l15) * 16;
             T a[EPV], b[NKQ][EPV];
+            if constexpr ((EXP & 8) != 0) { // EXP: fragments from registers, no LDS reads
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    a[e] = (T)(lane + e + kk);
+#pragma unroll
+                    for (int nt = 0; nt < NKQ; nt++) b[nt][e] = (T)(lane - e + nt);
+                }
+            } else {
             {
                 const int row = 16 * wave + l15;
                 const f32x4 raw = *(const f32x4 *)(buf + row * XPROD_ROWB + phys);
@@ -184,6 +198,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod_tn_kernel(const T *__rest
                 const int row = 16 * nt + l15;
                 const f32x4 raw = *(const f32x4 *)(buf + XPROD_A_IMG_BYTES + row * XPROD_ROWB + phys);
                 __builtin_memcpy(b[nt], &raw, 16);
+            }
             }
             T w[KT > 0 ? KT : 1][EPV];
             if constexpr (KT > 0) { // tail rows 16*NKQ + u: same 16-byte slot of the image row, uniform over the 16 lanes of a group

@@ -45,7 +45,7 @@ __device__ static inline void split16(float v, float scale, _Float16 &hi, _Float
 // Ring of XPROD_NBUF = 3 LDS stage buffers: two stages in flight while one is consumed, 144 KB at KP = 64 -- the block owns its CU.
 // (A two-buffer, 96 KB form that leaves room for a workgroup of the SCD sweep on the same CU was measured in round 4 -- DESIGN.md
 // section 6: co-residency hides 0.07 of 0.26 ms -- and is not kept.)
-template <int NKQ>
+template <int NKQ, int EXP = 0>
 __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_t *__restrict__ A16, int lda,   // lda: elements per column
                                                                    const uint32_t *__restrict__ Y16, int ldy,   // ldy: elements per row
                                                                    double *__restrict__ Cx, int ldc, size_t slab_stride,
@@ -60,10 +60,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
-    // (ablations of this kernel -- no MFMAs, re-read of a cached stage, late issue, descending order: scripts/exp/csrc_r5/k_xprod16.h with
-    //  scripts/exp/xprod_exp.hip / xerr_exp.hip; the product kernel carries no switch)
-    const int j0 = (int)blockIdx.x * XPROD_TN_BJ;
-    int st0 = stage_begin + (int)blockIdx.y * stages_per_split;
+    // (EXP bit 4, scripts/exp/xerr_exp.hip: tiles, slabs and stages in descending order -- does a pass find the end of the previous one in the infinity cache?)
+    const int j0 = ((EXP & 16) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * XPROD_TN_BJ;
+    int st0 = stage_begin + ((EXP & 16) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * stages_per_split;
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;
 
@@ -85,7 +84,8 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
     const unsigned long long baseA = xp_uniform64(A16 + (size_t)j0 * lda), baseY = xp_uniform64(Y16);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     auto issue = [&](int st, int bi) {
-        const unsigned long long c0b = (unsigned long long)st * 256ull; // byte offset of the chunk
+        const int sta = (EXP & 16) ? st1 - 1 - (st - st0) : st;
+        const unsigned long long c0b = (unsigned long long)((EXP & 4) && st > st0 + 1 ? st0 : sta) * 256ull; // byte offset of the chunk
         const unsigned dst = lds0 + (unsigned)bi * (unsigned)BUF + (unsigned)wave * 1024u;
 #pragma unroll
         for (int i = 0; i < XPROD_A_IMG_BYTES / 1024 / XPROD_WAVES; i++)
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
         wait_vmcnt((st + 1 < st1) ? per_stage : 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st + 2 < st1) issue(st + 2, (st + 2 - st0) % NBUF);
+        const bool late = (EXP & 8) && wave >= XPROD_WAVES / 2; // (experiment: half of the wavefronts issue behind their MFMA phase)
+        if (st + 2 < st1 && !late) issue(st + 2, (st + 2 - st0) % NBUF);
+        if (EXP & 2) continue;
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) { // two K = 32 chunks per stage; lane (l15, lg) holds elements 32*c2 + 8*lg .. +7
             const int arow = 16 * wave + l15;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_tn_kernel(const uint32_
                 accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh[nt], accx[nt], 0, 0, 0);
             }
         }
+        if (st + 2 < st1 && late) issue(st + 2, (st + 2 - st0) % NBUF);
         if (++since_flush == FL) {
             since_flush = 0;
 #pragma unroll
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
                                                                     int stage_end, int stages_per_split, const int *__restrict__ scal_exp,
                                                                     const int *__restrict__ w_exp, int n_rows, int n_cols,
                                                                     double *__restrict__ partial, unsigned *__restrict__ zero_word,
-                                                                    const uint32_t *__restrict__ missT = nullptr, int wordsT = 0, int i_off = 0)
+                                                                    const uint32_t *__restrict__ missT = nullptr, int wordsT = 0)
 {
     constexpr int FL = XPROD_FLUSH_ELEMS / 64;
     constexpr int NC2 = NKQ > 2 ? 2 : 1;                                   // 32-wide chunks of kq that can be non-zero
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(XPROD_THREADS) void xprod16_err_kernel(const uint32
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int rg = wave & 3; // rows 32 rg .. 32 rg + 31 of the block
-    const int i0 = i_off + blockIdx.x * XPROD_TN_BJ; // (i_off: first row of this rank's column shard -- multi-GPU, column form; 0 otherwise)
+    const int i0 = blockIdx.x * XPROD_TN_BJ;
     int st0 = stage_begin + blockIdx.y * stages_per_split;
     int st1 = st0 + stages_per_split;
     if (st1 > stage_end) st1 = stage_end;

@@ -1,6 +1,6 @@
 // Stand-alone timing of the strict-mode error kernels (not part of the product).  EXP bits via -DERR64_EXP=...:
 //   1 no logarithm / sums, 2 no MFMA phase, 4 no A loads
-#include "../../nnlm_amd/csrc/k_errors.h"
+#include "csrc_r5/k_errors.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

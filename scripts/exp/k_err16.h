@@ -8,7 +8,7 @@
 // kernel adds 0.107: next to a 272-register wavefront of the persistent sweep only ONE of its wavefronts fits on a SIMD (234 VGPRs; at
 // 168 it spills 236 bytes), and one wavefront cannot overlap its own load wait, barrier, 24 MFMAs and ~770 cycles of vector work per stage.
 #pragma once
-#include "../../nnlm_amd/csrc/k_xprod16.h"
+#include "csrc_r5/k_xprod16.h"
 
 // ---- the error block as a kernel of its own on the fp16 matrix cores (round 5) ---------------------------------------------------
 // xprod16_err_kernel above lets the error sums of a trace iteration ride in the speculative W half-step's cross product: +0.107 ms on

@@ -14,7 +14,7 @@
 // each slot to row q + 2 the moment it has read it back (the ONEBUF scheme of kl_tile_kernel); pass A of a(q+2), half a step
 // later, waits for piece e with a counted s_waitcnt.
 #pragma once
-#include "../../nnlm_amd/csrc/k_kl.h"
+#include "csrc_r5/k_kl.h"
 
 __host__ __device__ static inline size_t kl_tile2_lds_bytes(int p, int k, int C, int mw_masked = 0)
 {

@@ -11,7 +11,7 @@
 // row q has exactly E - 1 younger requests behind it whenever it is needed (E - 1 - e of its own row, e of row q + 1): ONE constant
 // s_waitcnt vmcnt(E - 1) per chunk.  The last update of the kernel is never applied (the state is not an output).
 #pragma once
-#include "../../nnlm_amd/csrc/k_kl.h"
+#include "csrc_r5/k_kl.h"
 
 template <int EPT4, int C, int METHOD>
 __global__ __launch_bounds__(KLT_THREADS) void kl_tile3_kernel(const KlTileArgs a)

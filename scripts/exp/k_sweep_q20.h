@@ -19,7 +19,7 @@
 // fp32-operand mode without masks only (the launch picks it when it saves a round: launch_sweep_q); same arithmetic, same
 // epilogue, same operand image as k_sweep_q.h plus a second image with the packed operands of set B.
 #pragma once
-#include "../../nnlm_amd/csrc/k_sweep_q.h"
+#include "csrc_r5/k_sweep_q.h"
 
 #define SWEEPQ20_COLS 80 // columns per workgroup: 20 per wavefront (16 + 4)
 

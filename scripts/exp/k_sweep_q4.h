@@ -19,7 +19,7 @@
 //     SAME shape overlap well (two 4-column wavefronts per SIMD: 148 us), two different instruction streams do not.
 // 6 % of the W half-step (1.6 % of an iteration) for a second operand image, a second kernel body and a launch split: not taken.
 #pragma once
-#include "../../nnlm_amd/csrc/k_sweep_q.h"
+#include "csrc_r5/k_sweep_q.h"
 
 #define SWEEPQ4_COLS 16 // columns per workgroup, 4 per wavefront
 #ifdef SWEEPQ_TRACE

@@ -8,7 +8,7 @@
 //     and -- in the shadow of those MFMAs -- the error arithmetic of tile t - 1 (the product form: all 56 MFMAs, then all of it);
 //   * interior stages (no edge tests) are one basic block; edge stages take the plain form.
 #pragma once
-#include "../../nnlm_amd/csrc/k_xprod16.h"
+#include "csrc_r5/k_xprod16.h"
 #include <type_traits>
 
 #define XE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)

@@ -2,7 +2,7 @@
 // at config 2 with random data against 0.42-0.45 for xprod_tn_kernel<double> with its late issue (one computing wavefront per SIMD does
 // not keep the fp64 matrix pipe as busy as two that take turns).
 #pragma once
-#include "../../nnlm_amd/csrc/k_xprod.h"
+#include "csrc_r5/k_xprod.h"
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..12
 __device__ static inline void xp_wait_vmcnt_rt(int n)

@@ -3,7 +3,7 @@
 //   ./klt_exp p ncols k method variant [reps] [sweeps]      variant 0: kl_tile_kernel, 2: kl_tile2_kernel
 // Inputs: A = U(0,1) fp32 [ncols][lda], fixed factor Yf = U(0,1) [k][lda], X = 0.5 + U(0,1) [64][ldx]; the starting states WtH come from a
 // plain device kernel.  Check: the first and last columns against an fp64 host restatement of lee_kl_update / scd_kl_update.
-#include "../../nnlm_amd/csrc/k_kl.h"
+#include "csrc_r5/k_kl.h"
 #include "k_kl2.h"
 #include "k_kl3.h"
 #include <cmath>

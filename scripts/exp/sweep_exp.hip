@@ -1,5 +1,5 @@
 // Ablation micro-benchmark of sweep_ls_kernel (not part of the product).  hipcc --offload-arch=gfx950 -O3 -o sweep_exp sweep_exp.hip
-#include "../../nnlm_amd/csrc/k_sweep.h"
+#include "csrc_r5/k_sweep.h"
 #include <cstdio>
 #include <vector>
 #include <random>

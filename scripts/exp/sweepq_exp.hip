@@ -2,8 +2,8 @@
 // SLABS=3: the cross product arrives as three split-K slabs, as in the iteration loop; GRAM=1: the epilogue leaves max|x| and Gram slabs; OP=1: fp32 operand copy
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o sweepq_exp sweepq_exp.hip ; ./sweepq_exp [ncols] [k] [max_iter]
 // #define SWEEPQ_DEBUG 1  (debug dumps: DUMP=col)
-#include "../../nnlm_amd/csrc/k_sweep.h"
-#include "../../nnlm_amd/csrc/k_sweep_q.h"
+#include "csrc_r5/k_sweep.h"
+#include "csrc_r5/k_sweep_q.h"
 #include "k_sweep_q4.h" // (experiment: four columns per wavefront, mixed launches)
 #include "k_sweep_q20.h" // (experiment only, not part of the product: 16 + 4 columns per wavefront -- measured, no gain)
 #include <cstdio>

@@ -6,9 +6,9 @@
 #ifndef FASTV
 #define FASTV true
 #endif
-#include "../../nnlm_amd/csrc/k_sweep_mfma.h"
-#include "../../nnlm_amd/csrc/k_sweep_wg.h"
-#include "../../nnlm_amd/csrc/k_sweep_wgf.h"
+#include "csrc_r5/k_sweep_mfma.h"
+#include "csrc_r5/k_sweep_wg.h"
+#include "csrc_r5/k_sweep_wgf.h"
 #include <cstdio>
 #include <cmath>
 #include <vector>

@@ -5,7 +5,7 @@
 //                                      2: the same with half of the wavefronts issuing late, 3..: k_xerr.h (xerr_launch)
 // Inputs are synthetic split-fp16 images written by a device kernel (values as the product's: hi in [2^14, 2^15) at most).  Check: the
 // cross product of every variant against variant 0 bit for bit, the two error sums to 1e-12 relative.
-#include "../../nnlm_amd/csrc/k_xprod16.h"
+#include "csrc_r5/k_xprod16.h"
 #include "k_xerr.h"
 #include <algorithm>
 #include <cmath>

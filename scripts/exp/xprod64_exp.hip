@@ -1,5 +1,5 @@
 // Ablation micro-benchmark of xprod_tn_kernel<double> in both half-step geometries (not part of the product).
-#include "../../nnlm_amd/csrc/k_xprod.h"
+#include "csrc_r5/k_xprod.h"
 #include "k_xprod64_rs.h"
 #include <cstdio>
 #include <cstdlib>

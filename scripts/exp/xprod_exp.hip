@@ -1,6 +1,6 @@
 // Ablation micro-benchmark of xprod_tn_kernel (not part of the product).
-#include "../../nnlm_amd/csrc/k_xprod.h"
-#include "../../nnlm_amd/csrc/k_xprod16.h"
+#include "csrc_r5/k_xprod.h"
+#include "csrc_r5/k_xprod16.h"
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
