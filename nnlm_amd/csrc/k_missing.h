@@ -12,7 +12,7 @@
 //     finite rows or  G_full - sum over missing rows  (complement), whichever touches fewer rows, from row lists made once per
 //     matrix: na_gram_f16_kernel (fp32-operand mode: split-fp16 rows, v_mfma_f32_16x16x32_f16) / na_gram_lds_kernel<double>
 //     (strict mode: fp64 rows gathered by LDS-DMA, v_mfma_f64_16x16x4_f64);
-//   * one wavefront per column, lane = coordinate, solves with that column's own G: colsolve_fast_kernel (SCD, fp32-operand
+//   * one wavefront per column, lane = coordinate, solves with that column's own G: colsolve_f32_kernel (SCD, fp32-operand
 //     mode: rows of G divided by their diagonal), colsolve_strict_kernel (SCD in the reference's arithmetic), colsolve_ls_kernel
 //     (Lee's multiplicative updates: lane r keeps column r of G_j in VGPRs, G[q][r] is an indirect VGPR read, x[q] a v_readlane).
 //
@@ -605,27 +605,21 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// colsolve_fast_kernel -- SCD-LS with a Gram of its own per column (or one shared Gram), fp32-operand mode (k <= 64).
+// colsolve_f32_kernel -- SCD-LS with a Gram of its own per column (or one shared Gram), fp32-operand mode (k <= 64).
 //
-// colsolve_ls_kernel above spends ~15 fp64 instructions per coordinate (four v_readlane pairs, reciprocal + Markstein
-// quotient, compare, select): 2.9 ms per half-step at config 5 against 0.19-0.24 ms for the dense sweep.  This kernel runs
-// the same recurrence in the arithmetic of the fp32-operand mode (k_sweep_q.h) (rows of G divided by their diagonal, nu = mu / G[q][q],
-// d = max(-x, -nu): ONE instruction) with one wavefront per column, lane = coordinate, and six instructions per step:
-//     v_max_f64   dd   = max(-x, -nu)              every lane on its own coordinate; lane q's value is the step's delta
-//     v_readlane  d    = dd[q]            (x2)      -> SGPR pair
-//     v_fma_f64   nu  += d * Gs[q]                  Gs[q] = G[lane][q] / G[lane][lane] lives in a register (q is unrolled)
-//     v_writelane xd[q] = d               (x2)      deltas of the sweep, added to x once per sweep
-// A coordinate's x only matters at its own step, so x is brought up to date once per sweep (x += xd) and the rel-change
-// test of src/base_algorithms.cpp:29-32 runs once per sweep on all lanes: 2|xd| > tol (x_new + x_old + eps).
-// Results differ from colsolve_ls_kernel by rounding only (the deviations listed for the fp32-operand mode in DESIGN.md section 2).
-// Also the dense sweep for SMALL column counts (multi-GPU column shards): its duration is 2500 steps x ~40 cycles however
-// few columns there are, a quarter of the workgroup-specialised kernel's.
-// KR: coordinates with a register of the Gram row (k <= KR <= 16 NKQ): k = 50 takes 52 instead of 64 -- 123 instead of 147 VGPRs, four
-// instead of three wavefronts per SIMD.
+// colsolve_ls_kernel above spends ~15 fp64 instructions per coordinate (four v_readlane pairs, reciprocal + Markstein quotient, compare,
+// select): 2.9 ms per half-step at config 5.  This kernel runs the same recurrence in the arithmetic of the fp32-operand mode (rows of G
+// divided by their diagonal, nu = mu / G[q][q], d = max(-x, -nu): ONE instruction) with one wavefront per column, lane = coordinate;
+// lane q alone takes its coordinate's step under an execution mask of one lane, the delta reaches every lane's gradient through an SGPR.
+// Rounds 2-5 ran the chain in fp64 (colsolve_fast_kernel, scripts/exp/csrc_r5/k_missing.h: five vector instructions per step, 104
+// registers of Gram row, 4 wavefronts per SIMD -- 0.33 / 0.66 ms per half-step at config 5).  Round 6 (the mode's contract is 1e-4 on
+// W, H; k_sweep_f.h): the chain on fp32 state.  The starting gradient nu0 = (G x - c + L1) / diag is still formed in fp64 (that is where the cancellation is) WHILE
+// the scaled Gram row is read, so no fp64 copy of the row is ever held; the row lives in KR fp32 registers (52 instead of 104 at k = 50:
+// 8 wavefronts per SIMD instead of 4); a step is four vector instructions instead of five (one v_readlane_b32), all of them fp32 (2.9
+// against 5.1 cycles per instruction and SIMD, scripts/exp/valu_exp.hip).
 template <int NKQ, bool HAS_MASK, int KR = 16 * NKQ>
-__global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, size_t g_stride)
+__global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, size_t g_stride)
 {
-    constexpr int KP = 16 * NKQ;
     const int lane = threadIdx.x & 63;
     const int col = a.col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= a.ncols) return; // whole wavefront
@@ -646,54 +640,63 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
         gd += NNLM_TINY;
     }
     const double rgd = 1.0 / gd;
-    double gs[KR]; // row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
-#pragma unroll
-    for (int q = 0; q < KR; q++) {
-        double v = 0.0;
-        if (q < k && lv) {
-            v = G[(size_t)q * a.KPg + lane];
-            if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
-            if (a.r1 != 0) v += a.r1;
-            if (q == lane) v += NNLM_TINY;
-            v *= rgd;
-        }
-        gs[q] = v;
-    }
-    double x = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
+    const double x64 = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
     double cv = 0.0;
     if (lv)
         for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)lq * a.ldc + col];
-    // nu = (G x - c + L1) / G[lane][lane]
-    double nu = lv ? (((a.r2 != 0) ? a.r2 - cv : -cv) * rgd) : 0.0;
+    // nu = (G x - c + L1) / G[lane][lane] in fp64, row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
+    // kept in fp32
+    double nu64 = lv ? (((a.r2 != 0) ? a.r2 - cv : -cv) * rgd) : 0.0;
+    float gs[KR];
 #pragma unroll
-    for (int q = 0; q < KR; q++)
-        if (q < k) nu = __builtin_fma(readlane_f64(x, q), gs[q], nu);
+    for (int q0 = 0; q0 < KR; q0 += 16) { // (16 fp64 loads in flight at a time: all KR at once would be the kernel's register peak)
+        double gv[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int q = q0 + e;
+            gv[e] = (q < KR && q < k && lv) ? G[(size_t)q * a.KPg + lane] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int q = q0 + e;
+            if (q < KR) {
+                double v = 0.0;
+                if (q < k && lv) {
+                    v = gv[e];
+                    if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
+                    if (a.r1 != 0) v += a.r1;
+                    if (q == lane) v += NNLM_TINY;
+                    v *= rgd;
+                }
+                float g32 = (float)v;
+                asm volatile("" : "+v"(g32)); // (a register of its own: left to the allocator, the 52 floats sit in the low halves of 52 register PAIRS)
+                gs[q] = g32;
+                if (q < k) nu64 = __builtin_fma(readlane_f64(x64, q), v, nu64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float x = (float)x64, nu = (float)nu64;
 
     unsigned t = 0;
     if (!skip) {
+        const float tol = (float)a.rel_tol, tole = tol * (float)NNLM_TINY;
         bool more = true; // rel = 1 + rel_tol > rel_tol
         for (; t < a.max_iter && more; t++) {
-            // Round 5: FIVE vector instructions per step.  Lane q alone takes its coordinate's step, under an execution mask of that one lane:
-            //     s_mov_b64  exec = {q}
-            //     v_max_f64  xd = max(-x, -nu)      (= max(0, x - nu) - x without the canonicalisation of fmax())
-            //     v_add_f64  x += xd
-            //     s_mov_b64  exec = all
-            // then the delta reaches every lane's gradient as before (2 v_readlane_b32 -> SGPR pair, v_fma_f64 nu += d * Gs[q]).  xd is ONE
-            // register through the sweep: a coordinate moves once per sweep, so at its end lane q still holds the delta of ITS step (masked
-            // coordinates their 0) -- what the two v_writelane_b32 of rounds 2-4 assembled.  The scalar moves go to the scalar unit, which
-            // idles beside this kernel; same operations on the same numbers: results are bit-identical.
-            const double x0 = x;
-            double xd = 0.0;
+            // a step:   s_mov_b64 exec = {q};  v_max_f32 xd = max(-x, -nu);  v_add_f32 x += xd;  s_mov_b64 exec = all;
+            //           v_readlane_b32 d = xd[q];  v_fma_f32 nu += d * Gs[q]
+            // xd is ONE register through the sweep: a coordinate moves once per sweep, so at its end lane q still holds the delta of ITS step
+            const float x0 = x;
+            float xd = 0.0f;
             int kk = k;
             asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
             auto step = [&](const int q) {
                 unsigned long long sv;
-                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %4\n\tv_max_f64 %0, -%1, -%3\n\tv_add_f64 %1, %1, %0\n\ts_mov_b64 exec, %2"
+                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %4\n\tv_max_f32 %0, -%1, -%3\n\tv_add_f32 %1, %1, %0\n\ts_mov_b64 exec, %2"
                              : "+v"(xd), "+v"(x), "=&s"(sv)
                              : "v"(nu), "s"(1ull << q));
-                int2 dp = __builtin_bit_cast(int2, xd);
-                const int dlo = __builtin_amdgcn_readlane(dp.x, q), dhi = __builtin_amdgcn_readlane(dp.y, q);
-                nu = __builtin_fma(__builtin_bit_cast(double, int2{dlo, dhi}), gs[q], nu);
+                const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xd), q));
+                nu = __builtin_fmaf(d, gs[q], nu);
             };
 #pragma unroll
             for (int c = 0; c < NKQ; c++) {
@@ -707,22 +710,24 @@ __global__ __launch_bounds__(256) void colsolve_fast_kernel(const SweepArgs a, s
                             if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
                 }
             }
-            const bool big = 2 * fabs(xd) > a.rel_tol * (x + x0 + NNLM_TINY); // src/base_algorithms.cpp:29-32 without the division
-            more = __ballot(big && lv) != 0ull || 0.0 > a.rel_tol;
+            const bool big = 2.0f * __builtin_fabsf(xd) > __builtin_fmaf(tol, x + x0, tole); // src/base_algorithms.cpp:29-32 without the division
+            more = __ballot(big && lv) != 0ull || 0.0f > tol;
         }
     }
     if (lv) {
-        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = x;
+        // (masked coordinates never took a step: their fp32 copy equals the rounded input -- hand the fp64 input back unchanged)
+        const double xo = (HAS_MASK && ((mword >> lane) & 1ull)) || skip ? x64 : (double)x;
+        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = xo;
         if (a.op_mode == 1) {
-            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = x;
-            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)x;
+            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = xo;
+            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)xo;
         }
     }
     if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
 
 // colsolve_strict_kernel -- SCD-LS per column in the REFERENCE's arithmetic (strict fp64 mode) with the structure of
-// colsolve_fast_kernel: one wavefront per column, lane = coordinate, row `lane` of the edited Gram in registers, the coordinate loop
+// colsolve_f32_kernel: one wavefront per column, lane = coordinate, row `lane` of the edited Gram in registers, the coordinate loop
 // fully unrolled.  Every lane evaluates the step of ITS coordinate from its own x, mu, G[lane][lane] -- tmp = max(x - mu / G, 0) with
 // the correctly rounded quotient (reciprocal + Markstein correction, k_sweep.h), d = tmp - x -- and lane q's d is the step's delta:
 // 2 v_readlane_b32 + 1 v_fma_f64 bring mu up to date (d = 0 when the reference skips the coordinate: adds nothing).  Lane q keeps

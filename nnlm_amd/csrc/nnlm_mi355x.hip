@@ -1487,7 +1487,8 @@ static void launch_colsolve_m(const SweepArgs &a, size_t g_stride, hipStream_t s
     colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
 }
 
-// F32 mode, SCD: colsolve_fast_kernel (scaled rows of G, six instructions per coordinate)
+// F32 mode, SCD: colsolve_f32_kernel (scaled rows of G in fp32 registers, four fp32 vector instructions per coordinate; its fp64-chain
+// predecessor colsolve_fast_kernel: scripts/exp/csrc_r5/k_missing.h)
 template <int NKQ>
 static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStream_t s)
 {
@@ -1495,12 +1496,12 @@ static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStrea
     if (nb <= 0) return;
     constexpr int KS = NKQ > 1 ? 16 * (NKQ - 1) + 4 : 16; // k = 16 j + 1 .. 16 j + 4: a Gram row of 16 j + 4 registers (k = 50: 52)
     if (NKQ > 1 && a.k <= KS) {
-        if (a.mask) colsolve_fast_kernel<NKQ, true, KS><<<nb, 256, 0, s>>>(a, g_stride);
-        else colsolve_fast_kernel<NKQ, false, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        if (a.mask) colsolve_f32_kernel<NKQ, true, KS><<<nb, 256, 0, s>>>(a, g_stride);
+        else colsolve_f32_kernel<NKQ, false, KS><<<nb, 256, 0, s>>>(a, g_stride);
         return;
     }
-    if (a.mask) colsolve_fast_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
-    else colsolve_fast_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
+    if (a.mask) colsolve_f32_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
+    else colsolve_f32_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
 }
 static bool colsolve_fast_ok(const nnlm_handle *h, int method)
 {
