@@ -108,6 +108,11 @@ typedef struct nnlm_handle nnlm_handle;
 /* device = HIP device ordinal; precision = NNLM_PREC_*.  Fails loudly when no gfx950 device exists. */
 int nnlm_create(nnlm_handle **out, int device, int precision);
 void nnlm_destroy(nnlm_handle *h);
+/* Process-wide caches: the streams / events / small buffers of the last destroyed handle wait for the next nnlm_create on the same
+ * device, and nnlm_set_matrix keeps its two pinned bounce buffers (up to 2 x 64 MB of pinned host memory).  Both are released at exit;
+ * an embedder that unloads the library earlier (the R package's .onUnload, pkg/src/r_glue.c) or wants the memory back calls this.
+ * Handles in use are not affected. */
+int nnlm_release_caches(void);
 const char *nnlm_last_error(const nnlm_handle *h); /* h may be NULL: error of the last failed nnlm_create / one-shot call */
 int nnlm_abi_version(void);
 
@@ -196,7 +201,9 @@ int nnlm_debug_partial(nnlm_handle *h, int which, double *G_out, double *C_out);
 int nnlm_debug_phase(nnlm_handle *h, int which, int phase, const double reg[3], unsigned inner_max_iter,
                      double inner_rel_tol, int method);
 int nnlm_debug_exchange(nnlm_handle **handles, int nranks, int which, int stage);
-/* Test hook: handles created from now on plan their launches as if the device had `cus` compute units (0 = the device's own
+/* The nnlm_debug_* entries are TEST HOOKS, not part of the production surface: process-global (atomic) settings read once per
+ * nnlm_create / allocation, never to be changed while another thread creates handles.
+ * Test hook: handles created from now on plan their launches as if the device had `cus` compute units (0 = the device's own
  * count) -- small problems then take the launch forms large ones take on the real device (persistent SCD sweep). */
 int nnlm_debug_set_cus(int cus);
 /* Test hook: the matrix-sized workspaces of the KL solvers (starting states of all columns, transposed copy of A, streaming scratch)
@@ -206,7 +213,9 @@ int nnlm_debug_alloc_limit(size_t bytes);
 /* Facts about the handle's last launches, for bench.py's kernel attribution: key = "cus" (compute units the launch policy
  * counts), "sweep_form_w" / "sweep_form_h" (SCD sweep of the last W / H half-step: 0 plain sweep_scd_q_kernel, 1 persistent
  * sweep_scd_qw_kernel -- both strict fp64 --, 2 sweep_scd_f_kernel (fp32-operand mode), -1 none yet), "sweep_groups_w" /
- * "sweep_groups_h" (column groups -- form 2: wavefronts -- per workgroup of that launch). */
+ * "sweep_groups_h" (column groups -- form 2: wavefronts -- per workgroup of that launch), "kl_form_w" / "kl_form_h" (KL solver of the
+ * last W / H half-step: 0 kl_tile_kernel on the starting states of the wh_store GEMM, 1 kl_tile_kernel forming its own starting states
+ * -- no room for the matrix-sized buffer --, 2 kl_reg64_kernel (strict), 3 kl_stream_kernel over column chunks, -1 none yet). */
 int nnlm_get_info(nnlm_handle *h, const char *key, double *value);
 
 #ifdef __cplusplus

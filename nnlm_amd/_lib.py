@@ -29,7 +29,7 @@ EXPORTS = [
     "nnlm_half_step", "nnlm_iterate", "nnlm_run", "nnlm_take_sweeps", "nnlm_errors", "nnlm_sync", "nnlm_profile_enable",
     "nnlm_profile_get", "nnlm_profile_reset", "nnlm_comm_unique_id", "nnlm_comm_init", "nnlm_comm_info",
     "nnlm_shard_range", "nnlm_shard_cols", "nnlm_debug_partial", "nnlm_debug_phase", "nnlm_debug_exchange",
-    "nnlm_comm_set_form", "nnlm_debug_set_cus", "nnlm_get_info", "nnlm_debug_alloc_limit",
+    "nnlm_comm_set_form", "nnlm_debug_set_cus", "nnlm_get_info", "nnlm_debug_alloc_limit", "nnlm_release_caches",
 ]
 
 
@@ -127,6 +127,8 @@ def load():
     lib.nnlm_debug_set_cus.argtypes = [C.c_int]
     lib.nnlm_debug_alloc_limit.restype = C.c_int
     lib.nnlm_debug_alloc_limit.argtypes = [C.c_size_t]
+    lib.nnlm_release_caches.restype = C.c_int
+    lib.nnlm_release_caches.argtypes = []
     lib.nnlm_get_info.restype = C.c_int
     lib.nnlm_get_info.argtypes = [vp, C.c_char_p, dp]
     _lib = lib
@@ -411,3 +413,8 @@ def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _check(load().nnlm_comm_unique_id(buf))
     return buf.raw
+
+
+def release_caches():
+    """Release the process-wide caches of the library (resources of the last destroyed handle, pinned bounce buffers)."""
+    _check(load().nnlm_release_caches())

@@ -238,23 +238,24 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
     // written out, a full wait in front of every LDS read when not) its counted waits for the A tile forced part of the NEXT
     // tile to land.  Piece = rows 2t (lanes 0..31) and 2t+1 (lanes 32..63), 16 bytes per lane, odd rows with their 128-byte halves
     // exchanged (see above).
-    const int half = lane >> 5;
-    const int lbyte = ((lane & 31) * 16) ^ (half << 7);
-    auto slice_load = [&](const double *X, int ld, int c0, f32x4 (&hr)[ERR64_HR]) {
+    auto slice_load = [&](const double *X, int ld, int c0, f32x4 (&hr)[ERR64_HR], int ln) {
+        const int half = ln >> 5;
+        const int lbyte = ((ln & 31) * 16) ^ (half << 7);
 #pragma unroll
         for (int u = 0; u < ERR64_HR; u++) {
             const int t = (wave + 4 * u < nch) ? wave + 4 * u : nch - 1; // (clamped, not skipped: a conditional load is sunk to its use)
             hr[u] = *(const f32x4 *)((const unsigned char *)(X + (size_t)(2 * t + half) * ld + c0) + lbyte);
         }
     };
-    auto slice_store = [&](unsigned char *dst, const f32x4 (&hr)[ERR64_HR]) {
+    auto slice_store = [&](unsigned char *dst, const f32x4 (&hr)[ERR64_HR], int ln) {
 #pragma unroll
         for (int u = 0; u < ERR64_HR; u++) {
             const int t = wave + 4 * u;
-            if (t < nch) *(f32x4 *)(dst + t * 1024 + lane * 16) = hr[u];
+            if (t < nch) *(f32x4 *)(dst + t * 1024 + ln * 16) = hr[u];
         }
     };
-    auto tile_a = [&](int jt, double (&av)[2][2][4], uint32_t (&mw)[2][4]) {
+    auto tile_a = [&](int jt, double (&av)[2][2][4], uint32_t (&mw)[2][4], int ln) {
+        const int l15 = ln & 15, lg = ln >> 4;
         // (addresses rebuilt from an opaque copy of the tile index: as induction variables of the tile loop the 24 of them were kept in
         //  registers -- 48 VGPRs -- and spilled)
         asm volatile("" : "+s"(jt));
@@ -285,16 +286,12 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         f32x4 wr[ERR64_HR];
 #pragma unroll
         for (int u = 0; u < ERR64_HR; u++) wr[u] = f32x4{0, 0, 0, 0};
-        slice_load(W64, ldw, i0, wr);
-        slice_load(H64, ldh, jt_begin * ERR_TILE, hr);
-        tile_a(jt_begin, av0, mw0);
-        slice_store(Ws, wr);
-        slice_store(Hs, hr);
+        slice_load(W64, ldw, i0, wr, lane);
+        slice_load(H64, ldh, jt_begin * ERR_TILE, hr, lane);
+        tile_a(jt_begin, av0, mw0, lane);
+        slice_store(Ws, wr, lane);
+        slice_store(Hs, hr, lane);
     }
-    const int swz = (lg & 1) << 7;
-    const unsigned char *wrow = Ws + lg * 512;
-    const int wo0 = ((ib + l15) * 8) ^ swz, wo1 = ((ib + 16 + l15) * 8) ^ swz;
-    const int ho0 = ((jb + l15) * 8) ^ swz, ho1 = ((jb + 16 + l15) * 8) ^ swz;
     const bool iedge = i0 + ERR_TILE > n;
 
     // One tile: [the slices written at the end of the last tile are visible] barrier [H slice of the next tile requested into
@@ -305,7 +302,17 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        slice_load(H64, ldh, jn * ERR_TILE, hr);
+        // With missing entries the lane number is taken afresh in every tile (two instructions) and everything that depends on it --
+        // slice / tile / LDS offsets -- is rebuilt from it: as loop invariants those ~20 registers were spilled next to the masked sums'
+        // working set, and every reload of a spilled register is a full vmcnt wait on gfx950.
+        int ln = lane;
+        if constexpr (HAS_MISS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int l15 = ln & 15, lg = ln >> 4;
+        const int swz = (lg & 1) << 7;
+        const unsigned char *wrow = Ws + lg * 512;
+        const int wo0 = ((ib + l15) * 8) ^ swz, wo1 = ((ib + 16 + l15) * 8) ^ swz;
+        const int ho0 = ((jb + l15) * 8) ^ swz, ho1 = ((jb + 16 + l15) * 8) ^ swz;
+        slice_load(H64, ldh, jn * ERR_TILE, hr, ln);
         const unsigned char *hrow = Hs + buf * slice_bytes + lg * 512;
         f64x4 acc[2][2];
 #pragma unroll
@@ -357,14 +364,17 @@ __global__ __launch_bounds__(ERR64_THREADS, ERR64_WPS) void errors64_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (redundant last reads)
 #undef E64_READ
 #undef E64_MMA
-        if constexpr (!HAS_MISS) tile_a(jn, avn, mwn); // (with missing entries: ONE register set, requested behind the sums -- see below)
+        if constexpr (!HAS_MISS) tile_a(jn, avn, mwn, ln); // (with missing entries: ONE register set, requested behind the sums -- see below)
+        // (with missing entries the H slice of the next tile leaves its registers BEFORE the sums: it was requested a whole matrix phase
+        //  ago, the other buffer has been free since this tile's barrier, and the masked sums need the 32 registers -- 25 spilled)
+        if constexpr (HAS_MISS) slice_store(Hs + (1 - buf) * slice_bytes, hr, ln);
         const bool masked = HAS_MISS || iedge || ((jt + 1) * ERR_TILE > m); // block uniform
         if (masked) errors64_sums<true>(acc, av, mw, n - i0 - ib, m - jt * ERR_TILE - jb, l15, lg, s2, skl, ltab);
         else errors64_sums<false>(acc, av, mw, 0, 0, l15, lg, s2, skl, ltab);
         // (the masked sums + the mask words + two sets of A spilled 136 .. 928 bytes: with missing entries the next tile is requested
         //  into the SAME set once this tile's sums are done; the next matrix phase covers most of its latency)
-        if constexpr (HAS_MISS) tile_a(jn, avn, mwn);
-        slice_store(Hs + (1 - buf) * slice_bytes, hr);
+        if constexpr (HAS_MISS) tile_a(jn, avn, mwn, ln);
+        else slice_store(Hs + (1 - buf) * slice_bytes, hr, ln);
     };
     int jt = jt_begin;
     for (; jt + 1 < jt_end; jt += 2) { // (pairs: the two register sets of A keep their names, no copies)

@@ -119,6 +119,14 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
 {
     constexpr int NV = (METHOD == 4) ? 1 : 2;
     constexpr int ELDS = EPT2 < KL64_ELDS_MAX ? EPT2 : KL64_ELDS_MAX, EREG = EPT2 - ELDS;
+    // SCD (two sums per column, their products) with two columns on 160 state registers does not fit 256: the allocator kept eleven
+    // chunks of b in scratch and reloaded them in every step, each reload a full vmcnt wait.  There the LAST chunks of the data columns
+    // (e >= EB) are not resident: pass A requests chunk e + BD from L2 while it works on chunk e (the block's re-read part of A stays
+    // in its XCD's L2).  (One column of 20 chunks: streaming made the allocator's choices worse -- see the pinned LDS reads below.)
+    constexpr bool BSTREAM = (METHOD == 3 && C == 2 && EPT2 >= 9);
+    constexpr int EB = BSTREAM ? EPT2 - 5 : EPT2;                        // first streamed chunk
+    constexpr int BD = 2;                                                // chunks ahead
+    static_assert(!BSTREAM || (EB >= BD && EPT2 - EB >= BD), "streamed chunks of b");
     extern __shared__ __attribute__((aligned(16))) unsigned char kl64_smem[];
     f64x2 *rowl = (f64x2 *)kl64_smem;                                  // [ELDS][512] this step's row, parked between the passes
     double *xs = (double *)(kl64_smem + (size_t)ELDS * KL64_THREADS * 16); // [C][k]
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
         xs[e] = (col < a.ncols) ? a.X[(size_t)q * a.ldx + col] : 0.0;
         sws[e] = (col < a.ncols) ? (a.sumw_cols ? a.sumw_cols[(size_t)col * a.ldsw + q] : a.sumw[q]) : 1.0;
     }
-    f64x2 y[C][EPT2], b[C][EPT2];
+    f64x2 y[C][EPT2], b[C][EB];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const int col = (col0 + c < a.ncols) ? col0 + c : col0;
@@ -142,9 +150,12 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
         for (int e = 0; e < EPT2; e++) {
             const int i2 = e * KL64_THREADS + tid;
             const bool valid = i2 < P2 && col0 + c < a.ncols;
-            b[c][e] = valid ? Ac[i2] : f64x2{0.0, 0.0};
+            if (e < EB) b[c][e < EB ? e : 0] = valid ? Ac[i2] : f64x2{0.0, 0.0};
             y[c][e] = valid ? Yc[i2] : f64x2{1.0, 1.0};
-            if (valid && 2 * i2 + 1 >= p) b[c][e][1] = 0.0, y[c][e][1] = 1.0; // (odd contraction length: the pad element)
+            if (valid && 2 * i2 + 1 >= p) {                                   // (odd contraction length: the pad element)
+                if (e < EB) b[c][e < EB ? e : 0][1] = 0.0;
+                y[c][e][1] = 1.0;
+            }
         }
     }
     // per-column bookkeeping, identical in every thread (block-uniform)
@@ -244,18 +255,44 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
             // chunk e of row q was requested e-th of ELDS LDS-DMAs (in order, during the previous step's pass B), the EREG plain loads
             // above come behind them: a COUNTED wait lets pass A start on chunk 0 while the rest of the row is still on its way
             // (one vmcnt(0) in front of the pass left the whole row fetch -- 160 KB per block from L2 -- exposed: 6.2 us per step)
+            // (streamed chunks of b: requests issued before chunk e's row wait are younger than every row request and stay outstanding)
             auto wfetch = [&](auto ec) -> f64x2 {
                 constexpr int e = decltype(ec)::value;
+                constexpr int nbs = BSTREAM ? C * ((e < EPT2 - BD ? e : EPT2 - BD) > EB - BD ? (e < EPT2 - BD ? e : EPT2 - BD) - (EB - BD) : 0) : 0;
                 if constexpr (e < ELDS) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ELDS - 1 - e + EREG) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ELDS - 1 - e + EREG + nbs) : "memory");
                     return rowl[e * KL64_THREADS + tl];
                 } else
                     return wreg[e - ELDS];
             };
-            auto pair4 = [&](int ea, int ca, const f64x2 &wa, int eb, int cb, const f64x2 &wb_) {
+            f64x2 bs[C][BD + 1];
+            auto brequest = [&](auto ec) { // chunk e + BD of the data column(s), unconditionally (clamped: a conditional load is sunk to its use)
+                constexpr int en = decltype(ec)::value + BD;
+                if constexpr (BSTREAM && en >= EB && en < EPT2) {
+                    const int i2 = en * KL64_THREADS + tl, i2c = i2 < P2 ? i2 : P2 - 1;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const int col = (col0 + c < a.ncols) ? col0 + c : col0;
+                        bs[c][en % (BD + 1)] = ((const f64x2 *)(a.Adata + (size_t)col * a.lda))[i2c];
+                    }
+                }
+            };
+            auto bget = [&](int c, auto ec) -> f64x2 {
+                constexpr int e = decltype(ec)::value;
+                if constexpr (e < EB) return b[c][e];
+                else {
+                    const int i2 = e * KL64_THREADS + tl;
+                    f64x2 r = bs[c][e % (BD + 1)];
+                    const bool valid = i2 < P2 && col0 + c < a.ncols;
+                    r[0] = valid ? r[0] : 0.0;
+                    r[1] = (valid && 2 * i2 + 1 < p) ? r[1] : 0.0;
+                    return r;
+                }
+            };
+            auto pair4 = [&](int ea, int ca, const f64x2 &wa, const f64x2 &ba, int eb, int cb, const f64x2 &wb_, const f64x2 &bb_) {
                 double num[4], den[4], r[4], t[4], qv[4];
                 const double wv[4] = {wa[0], wa[1], wb_[0], wb_[1]};
-                const double bv[4] = {b[ca][ea][0], b[ca][ea][1], b[cb][eb][0], b[cb][eb][1]};
+                const double bv[4] = {ba[0], ba[1], bb_[0], bb_[1]};
                 den[0] = y[ca][ea][0] + NNLM_TINY, den[1] = y[ca][ea][1] + NNLM_TINY, den[2] = y[cb][eb][0] + NNLM_TINY, den[3] = y[cb][eb][1] + NNLM_TINY;
 #pragma unroll
                 for (int i = 0; i < 4; i++) num[i] = (METHOD == 4) ? bv[i] : wv[i]; // Lee: Aj / (wh + eps), :141; SCD: mu = w / (Ajt + eps), :97
@@ -294,9 +331,11 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
                 klq_for<0, EPT2>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
                     const f64x2 w = wfetch(ec);
+                    brequest(ec);
+                    const f64x2 be = bget(0, ec);
                     double den[2] = {y[0][e][0] + NNLM_TINY, y[0][e][1] + NNLM_TINY}, num[2], r[2], t[2], qv[2];
 #pragma unroll
-                    for (int i = 0; i < 2; i++) num[i] = (METHOD == 4) ? b[0][e][i] : w[i];
+                    for (int i = 0; i < 2; i++) num[i] = (METHOD == 4) ? be[i] : w[i];
 #pragma unroll
                     for (int i = 0; i < 2; i++) r[i] = __builtin_amdgcn_rcp(den[i]);
 #pragma unroll
@@ -317,7 +356,7 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
                         v[0][0] = __builtin_fma(w[0], qv[0], v[0][0]);
                         v2[0][0] = __builtin_fma(w[1], qv[1], v2[0][0]);
                     } else {
-                        const double bu0 = b[0][e][0] * qv[0], bu1 = b[0][e][1] * qv[1];
+                        const double bu0 = be[0] * qv[0], bu1 = be[1] * qv[1];
                         v[0][0] = __builtin_fma(bu0, qv[0], v[0][0]), v[0][1] += bu0;
                         v2[0][0] = __builtin_fma(bu1, qv[1], v2[0][0]), v2[0][1] += bu1;
                     }
@@ -328,15 +367,16 @@ __global__ __launch_bounds__(KL64_THREADS) void kl_reg64_kernel(const Kl64Args a
                 klq_for<0, EPT2 / 2>([&](auto gc) {
                     constexpr int e = 2 * decltype(gc)::value;
                     const f64x2 wa = wfetch(std::integral_constant<int, e>{}), wb_ = wfetch(std::integral_constant<int, e + 1>{});
-                    pair4(e, 0, wa, e + 1, 0, wb_);
+                    pair4(e, 0, wa, b[0][e], e + 1, 0, wb_, b[0][e + 1]); // (EPT2 < 18: every chunk of b resident)
                     __builtin_amdgcn_sched_barrier(0); // (keeps the compiler from hoisting later chunks' LDS reads: 160 state registers leave no room)
                 });
             } else {
                 klq_for<0, EPT2>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
                     const f64x2 w = wfetch(ec);
+                    brequest(ec);
 #pragma unroll
-                    for (int c = 0; c < C; c += 2) pair4(e, c, w, e, c + 1, w);
+                    for (int c = 0; c < C; c += 2) pair4(e, c, w, bget(c, ec), e, c + 1, w, bget(c + 1, ec));
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
@@ -524,7 +564,8 @@ __global__ __launch_bounds__(256) void wh_store64_kernel(const double *__restric
 struct KlTileArgs {
     const float *Adata; // column c at Adata + c * lda, contraction index contiguous
     size_t lda;         // (= ldyf, a multiple of 4)
-    const float *Yinit; // same layout: starting state vectors y = Yt^T x of all columns (wh_store_kernel)
+    const float *Yinit; // same layout: starting state vectors y = Yt^T x of all columns (wh_store_kernel), or NULL (two row buffers only):
+                        // the block forms them itself from the rows of the fixed factor before its first step
     const float *Yf;    // [k][ldyf] fp32 fixed factor, contraction index contiguous, zero beyond p
     int ldyf;
     int p, ncols, k;
@@ -685,17 +726,20 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
         sws[e] = (col < a.ncols) ? (a.sumw_cols ? a.sumw_cols[(size_t)col * a.ldsw + q] : a.sumw[q]) : 1.0;
     }
 
+    const bool own_init = !ONEBUF && a.Yinit == nullptr; // block-uniform
     f32x4 y[C][EPT4], b[C][EPT4];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const int col = (col0 + c < a.ncols) ? col0 + c : col0;
-        const f32x4 *Ac = (const f32x4 *)(a.Adata + (size_t)col * a.lda), *Yc = (const f32x4 *)(a.Yinit + (size_t)col * a.lda);
+        const f32x4 *Ac = (const f32x4 *)(a.Adata + (size_t)col * a.lda);
+        const f32x4 *Yc = own_init ? Ac : (const f32x4 *)(a.Yinit + (size_t)col * a.lda);
 #pragma unroll
         for (int e = 0; e < EPT4; e++) {
             const int idx4 = e * NT + tid;
             const bool valid = KLT_HAS(e) && idx4 < L4 && col0 + c < a.ncols;
             b[c][e] = valid ? Ac[idx4] : f32x4{0.f, 0.f, 0.f, 0.f};
-            y[c][e] = valid ? Yc[idx4] : f32x4{1.f, 1.f, 1.f, 1.f};
+            if (ONEBUF || !own_init) y[c][e] = valid ? Yc[idx4] : f32x4{1.f, 1.f, 1.f, 1.f};
+            else y[c][e] = valid ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{1.f, 1.f, 1.f, 1.f};
         }
     }
     // All 4 C EPT4 loads are in flight together; a register use of every one of them HERE (once): otherwise the compiler puts
@@ -703,11 +747,41 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
 #pragma unroll
     for (int c = 0; c < C; c++)
 #pragma unroll
-        for (int e = 0; e < EPT4; e++) {
-            asm volatile("" : "+v"(b[c][e]), "+v"(y[c][e]));
-            y[c][e] = y[c][e] + tiny;
-        }
+        for (int e = 0; e < EPT4; e++) asm volatile("" : "+v"(b[c][e]), "+v"(y[c][e]));
     __syncthreads();
+    int bufsel = 0;
+    if constexpr (!ONEBUF) {
+        // Starting states formed here, y = sum_q x[q] * (row q of the fixed factor) -- the k rows come through the two row buffers
+        // exactly as in the step loop (the last step requests row 0 for the first coordinate step): one fused multiply-add per element and
+        // coordinate, against a GEMM kernel that writes a matrix-sized buffer this kernel then reads back (wh_store_kernel).
+        if (own_init) {
+            issue(0, 0);
+            for (int q = 0; q < k; q++) {
+                const int qn = (q + 1 < k) ? q + 1 : 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned char *rowi = kl_smem + (size_t)bufsel * rowb;
+                const int nbuf = bufsel ^ 1;
+                bufsel ^= 1;
+                float xc[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) xc[c] = (float)xs[c * k + q];
+#pragma unroll
+                for (int e = 0; e < EPT4; e++) {
+                    if (KLT_HAS(e)) {
+                        const f32x4 w = *(const f32x4 *)(rowi + (size_t)(e * NT + tid) * 16);
+                        issue_piece(qn, nbuf, e);
+#pragma unroll
+                        for (int c = 0; c < C; c++) y[c][e] = __builtin_elementwise_fma(f32x4{xc[c], xc[c], xc[c], xc[c]}, w, y[c][e]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < EPT4; e++) y[c][e] = y[c][e] + tiny;
 #if KLT_TIMING
     // T[i] += cycles since the previous mark: 0 prologue / loop overhead, 1 top of the step (row wait, LDS reads of the coordinate), 2 pass A,
     // 3 wave totals, 4 barrier, 5 scalar part, 6 pass B, 7 epilogue
@@ -729,8 +803,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
     unsigned tdone_l = 0;
     bool run_l = live_l && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol, flag_l = false;
     bool any = (__ballot(run_l) & cmask) != 0ull;
-    int par = 0, bufsel = 0;
-    if (any) issue(0, 0);
+    int par = 0;
+    if (any && !own_init) issue(0, 0); // (own_init: row 0 is already on its way into buffer `bufsel`)
     while (any) { // block-uniform: every wavefront holds the same per-lane column state
         flag_l = 0.0 > a.rel_tol; // rel_err starts each sweep at 0 (src/base_algorithms.cpp:93,137)
         for (int q = 0; q < k; q++) {

@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -56,6 +57,7 @@ struct nnlm_handle {
     int cus = 256;              // compute units of the device (sweep launch policy: one wavefront of the SCD sweep per SIMD, 4 SIMDs per CU)
     int sweep_wgs = 0;          // workgroups of the last sweep_scd_q(w)_kernel launch = Gram partial-sum slabs it left behind
     int cur_which = 1;          // the half-step in progress (0: W, 1: H)
+    int kl_form[2] = {-1, -1}; // per half-step: its last KL solver launch (0 tile kernel on the GEMM's states, 1 tile kernel on its own states, 2 strict register kernel, 3 streaming)
     int sweep_form[2] = {-1, -1}, sweep_groups[2] = {0, 0}; // per half-step (0: W, 1: H): form of its last SCD sweep launch (0 plain, 1 persistent) and
                                                              // column groups per workgroup (nnlm_get_info)
     int prec = NNLM_PREC_F32;
@@ -94,6 +96,9 @@ struct nnlm_handle {
     double *klsw = nullptr, *klsw_cols = nullptr; // KL: row sums of the fixed factor [KP] / per column over its non-missing entries [cols][KP]
     void *klst = nullptr;                         // kl_stream_kernel: [cols][2][ld] state vectors + data columns
     size_t klst_bytes = 0;
+    bool what_tight = false;                      // the matrix-sized What / What64 could not be had for this matrix (not retried every half-step)
+    bool klst_tight = false;                      // the full-size streaming scratch could not be had: the chunked one is kept
+    bool at_tight = false;                        // the transposed copy AT could not be had (soft request of the KL solvers)
 
     // workspaces
     double *Cx = nullptr;
@@ -299,7 +304,7 @@ extern "C" unsigned nnlm_trace_capacity(unsigned max_iter, unsigned trace)
     return (unsigned)std::ceil((double)max_iter / (double)trace) + 1; // src/nnmf.cpp:53-54
 }
 
-static int g_debug_cus = 0; // nnlm_debug_set_cus: compute units the launch policies of new handles count (0 = the device's)
+static std::atomic<int> g_debug_cus{0}; // nnlm_debug_set_cus (test hook, read once per nnlm_create): compute units the launch policies of new handles count (0 = the device's)
 // Pinned bounce buffers of nnlm_set_matrix, kept between calls.  Pinning costs ~0.3 ms per MB: two fresh 64 MB buffers were ~40 ms of EVERY
 // upload (half of config 2's 78 ms, most of the 53 ms an 80 MB matrix took -- scripts/gpu_call_breakdown.py).  One pair per process, taken
 // by the call that finds it free (a concurrent upload on another thread allocates its own and frees it), released at exit.
@@ -367,14 +372,15 @@ static void bounce_give_back(double *buf[2], bool cached)
     buf[0] = buf[1] = nullptr;
 }
 
-static size_t g_debug_alloc_limit = 0; // nnlm_debug_alloc_limit: matrix-sized KL workspaces beyond this many bytes "do not fit" (0 = no limit)
+static std::atomic<size_t> g_debug_alloc_limit{0}; // nnlm_debug_alloc_limit (test hook): matrix-sized KL workspaces beyond this many bytes "do not fit" (0 = no limit)
 
 // Matrix-sized workspaces of the KL solvers (starting states of all columns, transposed copy of A, streaming scratch): the callers have
 // a smaller-footprint path when one of them cannot be had, so a failure here is an answer, not an error.
 static hipError_t big_malloc(void **p, size_t bytes)
 {
     *p = nullptr;
-    if (g_debug_alloc_limit && bytes > g_debug_alloc_limit) return hipErrorOutOfMemory;
+    const size_t lim = g_debug_alloc_limit.load(std::memory_order_relaxed);
+    if (lim && bytes > lim) return hipErrorOutOfMemory;
     const hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -452,18 +458,25 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         h->device = device;
         h->prec = precision;
         h->cus = h->cus_device = res.cus;
-        if (g_debug_cus > 0) h->cus = g_debug_cus;
+        if (const int dc = g_debug_cus.load(std::memory_order_relaxed); dc > 0) h->cus = dc;
         h->stream = res.stream, h->stream_e = res.stream_e;
         h->ev_hdone = res.ev_hdone, h->ev_err = res.ev_err, h->ev_xdone = res.ev_xdone;
         h->scal = res.scal, h->sweeps = res.sweeps, h->host_res = res.host_res, h->sweeps_tmp = res.sweeps_tmp, h->sweepq_img = res.sweepq_img;
         h->maxbits = res.maxbits, h->scal_exp = res.scal_exp;
-        hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
-        hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
-        hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream);
-        hipStreamSynchronize(h->stream);
-        h->x16 = x16_enabled(precision);
-        *out = h;
-        return NNLM_OK;
+        // (inherited streams may be dead -- hipDeviceReset by the host application, a fork, a sticky error raised after the destroy: a
+        //  cached set that does not answer is dropped and the call goes on to create a fresh one)
+        const bool alive = hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream) == hipSuccess &&
+                           hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream) == hipSuccess &&
+                           hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream) == hipSuccess &&
+                           hipStreamSynchronize(h->stream) == hipSuccess && hipStreamSynchronize(h->stream_e) == hipSuccess;
+        if (alive) {
+            h->x16 = x16_enabled(precision);
+            *out = h;
+            return NNLM_OK;
+        }
+        (void)hipGetLastError();
+        delete h; // (a plain object at this point: the resources are still `res`'s)
+        handle_res_destroy(res);
     }
     hipDeviceProp_t prop;
     HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
@@ -474,7 +487,7 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
     h->prec = precision;
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->cus_device = h->cus;
-    if (g_debug_cus > 0) h->cus = g_debug_cus; // test hook (nnlm_debug_set_cus): the sweep's launch policy at small sizes
+    if (const int dc = g_debug_cus.load(std::memory_order_relaxed); dc > 0) h->cus = dc; // test hook (nnlm_debug_set_cus): the sweep's launch policy at small sizes
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_e, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_hdone, hipEventDisableTiming) != hipSuccess ||
@@ -491,12 +504,36 @@ extern "C" int nnlm_create(nnlm_handle **out, int device, int precision)
         delete h;
         return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: hipMalloc failed");
     }
-    hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream);
-    hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream);
-    hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream);
-    hipStreamSynchronize(h->stream);
+    if (hipMemsetAsync(h->sweeps, 0, 2 * sizeof(unsigned long long), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->scal_exp, 0, 4 * sizeof(int), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->maxbits, 0, 16 * sizeof(unsigned), h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        const hipError_t em = hipGetLastError();
+        HandleRes dead; // (not through nnlm_destroy: it would offer these resources to the next create)
+        dead.stream = h->stream, dead.stream_e = h->stream_e, dead.ev_hdone = h->ev_hdone, dead.ev_err = h->ev_err, dead.ev_xdone = h->ev_xdone;
+        dead.scal = h->scal, dead.sweeps = h->sweeps, dead.host_res = h->host_res, dead.sweeps_tmp = h->sweeps_tmp, dead.sweepq_img = h->sweepq_img;
+        dead.maxbits = h->maxbits, dead.scal_exp = h->scal_exp;
+        delete h;
+        handle_res_destroy(dead);
+        return fail(nullptr, NNLM_ERR_HIP, "nnlm_create: clearing the handle's counters failed: %s", hipGetErrorString(em));
+    }
     h->x16 = x16_enabled(precision);
     *out = h;
+    return NNLM_OK;
+}
+
+// The process-wide caches (the streams / events / scratch of the last destroyed handle, the pinned bounce buffers of nnlm_set_matrix: up to
+// 2 x 64 MB of pinned host memory) are released at exit; an embedder that unloads the library earlier (an R package's .onUnload hook)
+// or wants the pinned memory back calls this.  Handles in use are not affected.
+extern "C" int nnlm_release_caches(void)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (g_res.valid) handle_res_destroy(g_res);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_bounce_mu);
+        if (!g_bounce_busy) bounce_release_at_exit();
+    }
     return NNLM_OK;
 }
 
@@ -536,6 +573,7 @@ static void free_factors(nnlm_handle *h)
     h->klsw = h->klsw_cols = nullptr;
     h->klst = nullptr;
     h->klst_bytes = 0;
+    h->what_tight = h->klst_tight = false; // (another rank, other workspace sizes: asked again)
     hipFree(h->Y16);
     hipFree(h->W16c);
     hipFree(h->H16c);
@@ -571,6 +609,7 @@ static void free_matrix(nnlm_handle *h)
     hipFree(h->A);
     hipFree(h->AT);
     h->AT = nullptr;
+    h->what_tight = h->klst_tight = h->at_tight = false; // (what did not fit beside the last matrix may fit beside the next)
     hipFree(h->A16);
     hipFree(h->A16T);
     h->A16 = h->A16T = nullptr;
@@ -1738,12 +1777,34 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
     // the W half-step: slow, and the reference's arithmetic either way) -- an allocation that fails here is not an error.
     bool tile_path = h->prec == NNLM_PREC_F32 && kl_tile_fits(a.p, h->k, a.mask ? h->MW : 0);
     bool reg64_path = h->prec == NNLM_PREC_F64 && !generic_rank(h) && kl64_fits(a.p, h->k);
-    if (tile_path && !h->What && big_malloc((void **)&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096) != hipSuccess) tile_path = false;
-    if (reg64_path && !h->What64 && big_malloc((void **)&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096) != hipSuccess) reg64_path = false;
+    // No room for the matrix-sized What: with two row buffers (contractions up to 20480) kl_tile_kernel forms its starting states itself
+    // from the rows of the fixed factor -- 8-12 % slower than the GEMM + read-back at config 3 (4.67 -> 5.03 ms per step,
+    // profiles/r06_kl_own_init_ab.log), far ahead of the streaming kernel.  `what_tight` keeps a failed allocation from being retried in
+    // every half-step; nnlm_set_matrix clears it.
+    bool kl_own_init = false;
+    if (tile_path && !h->What) {
+        if (h->what_tight || big_malloc((void **)&h->What, (size_t)h->npad * h->mpad * sizeof(float) + 4096) != hipSuccess) {
+            h->what_tight = true;
+            if (kl_tile_nbuf(kl_tile_ept4(a.p)) == 2) kl_own_init = true;
+            else tile_path = false;
+        }
+    }
+    if (reg64_path && !h->What64 &&
+        (h->what_tight || big_malloc((void **)&h->What64, (size_t)h->npad * h->mpad * sizeof(double) + 4096) != hipSuccess)) {
+        h->what_tight = true;
+        reg64_path = false;
+    }
     if ((tile_path || reg64_path) && which == 0) {
-        const int rc = ensure_AT(h, true);
-        if (rc == NNLM_ERR_UNSUPPORTED) tile_path = reg64_path = false;
-        else if (rc != NNLM_OK) return rc;
+        const int rc = h->at_tight ? NNLM_ERR_UNSUPPORTED : ensure_AT(h, true);
+        if (rc == NNLM_ERR_UNSUPPORTED) {
+            // the W half-step goes to the streaming kernel: the matrix-sized starting-state buffer is exactly the memory its scratch
+            // needs (the H half-step then forms its states itself / streams too), and the failing allocation is not retried every half-step
+            h->at_tight = true;
+            tile_path = reg64_path = kl_own_init = false;
+            hipFree(h->What), hipFree(h->What64);
+            h->What = nullptr, h->What64 = nullptr;
+            h->what_tight = true;
+        } else if (rc != NNLM_OK) return rc;
     }
     if (tile_path) {
         // ---- fp32-operand mode: register-resident state, rows of the fixed factor staged through LDS (kl_tile_kernel) ----
@@ -1761,7 +1822,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         const size_t cofs = (size_t)ct0 * ERRF_TILE;
         if (which == 1) {
             const int nx = h->npad / ERRF_TILE;
-            if (ny > 0)
+            if (ny > 0 && !kl_own_init)
                 wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>((const float *)h->Wop, h->npad, h->Hkq + cofs, h->mpad, k2,
                                                                                      h->What + cofs * h->npad, h->npad, nx);
             ta.Adata = (const float *)h->A;
@@ -1770,14 +1831,14 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
             int rc = ensure_AT(h);
             if (rc != NNLM_OK) return rc;
             const int nx = h->mpad / ERRF_TILE;
-            if (ny > 0)
+            if (ny > 0 && !kl_own_init)
                 wh_store_kernel<<<8u * ((nx + 7) / 8) * ny, 256, lds, h->stream>>>(h->Hkq, h->mpad, (const float *)h->Wop + cofs, h->npad, k2,
                                                                                      h->What + cofs * h->mpad, h->mpad, nx);
             ta.Adata = (const float *)h->AT;
             ta.Yf = h->Hkq;
         }
         ta.lda = (size_t)ld_con;
-        ta.Yinit = h->What;
+        ta.Yinit = kl_own_init ? nullptr : h->What;
         ta.ldyf = ld_con;
         ta.p = a.p;
         ta.ncols = a.ncols;
@@ -1816,6 +1877,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ta.op_ld = a.op_ld;
         ta.sweeps = a.sweeps;
         launch_kl_tile(method, ta, h->stream);
+        h->kl_form[which] = kl_own_init ? 1 : 0;
     } else if (reg64_path) {
         // ---- strict fp64 mode: register-resident fp64 state, the row of the fixed factor parked in LDS between the passes ----
         Kl64Args ka;
@@ -1880,6 +1942,7 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         ka.op_ld = a.op_ld;
         ka.sweeps = a.sweeps;
         launch_kl64(method, ka, h->stream);
+        h->kl_form[which] = 2;
     } else {
         // ---- no size limits: state vectors and data columns streamed from a scratch buffer (kl_stream_kernel), `chunk` columns at a
         // time: the whole range when the scratch for it can be had (two vectors per column), otherwise as many as fit
@@ -1887,7 +1950,10 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
         const int range = a.ncols > a.col0 ? a.ncols - a.col0 : 0;
         int chunk = range;
         if (range > 0 && h->klst_bytes < (size_t)range * per_col) {
-            if (h->klst_bytes >= (size_t)64 * per_col && h->klst_bytes / per_col >= (size_t)range / 8) // (a scratch of an earlier, tighter time: keep it)
+            // A smaller scratch is kept only once an allocation of the full size has actually failed for this matrix (`klst_tight`):
+            // otherwise the two half-steps of an iteration, whose sizes differ slightly (n x mpad against m x npad), would have the
+            // larger one split into a full launch + a tail launch of a few columns in every iteration.
+            if (h->klst_tight && h->klst_bytes >= (size_t)64 * per_col && h->klst_bytes / per_col >= (size_t)range / 8)
                 chunk = (int)(h->klst_bytes / per_col);
             else {
                 hipFree(h->klst);
@@ -1895,11 +1961,13 @@ static int half_step_kl(nnlm_handle *h, int which, const double reg[3], unsigned
                 h->klst_bytes = 0;
                 for (;; chunk = (chunk + 1) / 2) {
                     if (big_malloc(&h->klst, (size_t)chunk * per_col) == hipSuccess) break;
+                    h->klst_tight = true;
                     if (chunk <= 64) return fail(h, NNLM_ERR_HIP, "KL solver: no scratch for even %d columns (%zu bytes)", chunk, (size_t)chunk * per_col);
                 }
                 h->klst_bytes = (size_t)chunk * per_col;
             }
         }
+        h->kl_form[which] = 3;
         const int col_end = a.ncols;
         for (int c0 = a.col0; c0 < col_end; c0 += chunk) {
             KlArgs ac = a;
@@ -2696,6 +2764,8 @@ extern "C" int nnlm_get_info(nnlm_handle *h, const char *key, double *value)
     else if (strcmp(key, "sweep_form_h") == 0) *value = h->sweep_form[1];
     else if (strcmp(key, "sweep_groups_w") == 0) *value = h->sweep_groups[0];
     else if (strcmp(key, "sweep_groups_h") == 0) *value = h->sweep_groups[1];
+    else if (strcmp(key, "kl_form_w") == 0) *value = h->kl_form[0];
+    else if (strcmp(key, "kl_form_h") == 0) *value = h->kl_form[1];
     else return fail(h, NNLM_ERR_ARG, "nnlm_get_info: unknown key '%s'", key);
     return NNLM_OK;
 }

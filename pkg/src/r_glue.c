@@ -156,3 +156,11 @@ void R_init_NNLM(DllInfo *dll)
     R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
     R_useDynamicSymbols(dll, FALSE);
 }
+
+/* R calls this when the package's shared object is unloaded (library.dynam.unload / detach(unload = TRUE)): the device library keeps
+ * streams, events and pinned bounce buffers between calls (nnlm_release_caches, include/nnlm_mi355x.h) -- they go with the package. */
+void R_unload_NNLM(DllInfo *dll)
+{
+    (void)dll;
+    (void)nnlm_release_caches();
+}

@@ -1,5 +1,5 @@
-"""Time the stand-alone error block (errors_f32_kernel) at BASELINE sizes, dense and with 10 % missing entries, and check its two
-sums against a host evaluation in fp64 (GPU box only)."""
+"""Time the stand-alone error block (errors_f32_kernel; `gpu_err_time.py f64`: errors64_kernel) at BASELINE sizes, dense and with 10 %
+missing entries, and check its two sums against a host evaluation in fp64 (GPU box only)."""
 import os
 import sys
 import time
@@ -11,6 +11,7 @@ import nnlm_amd  # noqa: E402
 from nnlm_amd import _lib  # noqa: E402
 
 N, M, K = 20000, 10000, 50
+PREC = _lib.PREC_F64 if "f64" in sys.argv[1:] else _lib.PREC_F32
 rng = np.random.default_rng(1)
 A = rng.random((N, M))
 W, H = rng.random((N, K)) * 0.2, rng.random((K, M)) * 0.2
@@ -18,7 +19,7 @@ for tag in ("dense", "na"):
     if tag == "na":
         A = A.copy()
         A.ravel()[np.random.default_rng(7).choice(N * M, N * M // 10, replace=False)] = np.nan
-    with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
+    with nnlm_amd.Handle(0, PREC) as h:
         h.set_matrix(A)
         h.set_factors(K, W, H)
         mse, kl, _ = h.errors()

@@ -135,6 +135,21 @@ def test_default_precision_of_the_one_shot_entries_is_fp64(monkeypatch):
     assert 1e-12 < np.max(np.abs(r32["coefficient"].ravel() - b)) < 1e-4
 
 
+def test_release_caches_between_one_shot_calls_changes_nothing(monkeypatch):
+    """nnlm_release_caches (the R package's unload hook): the streams / events / bounce buffers a destroyed handle left behind go, the
+    next one-shot call creates fresh ones and returns the same factors; calling it twice, or with nothing cached, is fine."""
+    monkeypatch.delenv("NNLM_PRECISION", raising=False)
+    A, W0, H0 = _problem(seed=11)
+    args = (A, 4, W0, H0, None, None, [0, 0, 0], [0, 0, 0], 30, -1.0, 1, 0, False, 10, 1e-6, 1, 1)
+    r1 = nnlm_amd.c_nnmf(*args)
+    _lib.release_caches()
+    _lib.release_caches()
+    r2 = nnlm_amd.c_nnmf(*args)
+    assert np.array_equal(r1["W"], r2["W"]) and np.array_equal(r1["H"], r2["H"])
+    r3 = nnlm_amd.c_nnmf(*args)  # (on the cached resources of r2's handle)
+    assert np.array_equal(r1["W"], r3["W"])
+
+
 # ---- stacked known profiles, masks, W.norm through the R-interface mirror ------------------------------------------
 @pytest.mark.parametrize("pname,tol", [("f64", 1e-8), ("f32", 1e-4)])
 def test_known_profiles_and_masks_stacked_like_reformat_input(monkeypatch, pname, tol):

@@ -184,7 +184,8 @@ def test_kl_half_steps_take_the_streaming_path_when_their_workspaces_do_not_fit(
     that fails sends the half-step to kl_stream_kernel over column CHUNKS with whatever scratch can be had.  nnlm_debug_alloc_limit makes
     workspaces beyond 1 MB "not fit": What (1.5 / 3 MB) and AT fail, the full streaming scratch (4 - 9 MB) fails, a chunk of ~60 columns
     fits -- eight launches per half-step.  Same factors as the roomy run (same reference arithmetic, another summation order) and as the
-    oracle; the handle keeps working when the limit is lifted."""
+    oracle; the handle keeps working when the limit is lifted.  (Round 6, fp32-operand mode: without What the H half-steps stay on
+    kl_tile_kernel, which then forms its starting states itself; the W half-steps, without the transposed copy, stream.)"""
     rng, A, W0, H0 = _planted(900 + method + (7 if na else 0), 700, 500, 6)
     if na:
         A[rng.random(A.shape) < 0.12] = np.nan
@@ -209,6 +210,52 @@ def test_kl_half_steps_take_the_streaming_path_when_their_workspaces_do_not_fit(
     assert s1 == s2
     o = ref.c_nnmf(A, 6, W0, H0, None, None, reg, reg, 2, -1.0, 0, 0, False, inner, 1e-9, method, 2)
     assert relF(W2, o["W"]) < tol and relF(H2, o["H"]) < tol, (relF(W2, o["W"]), relF(H2, o["H"]))
+
+
+@pytest.mark.parametrize("method", [3, 4])
+@pytest.mark.parametrize("shape", [(700, 500, 6), (2100, 1030, 50), (300, 4200, 17)])
+@pytest.mark.parametrize("na,masked", [(False, False), (True, True)])
+def test_kl_tile_kernel_forms_its_own_starting_states_when_what_does_not_fit(method, shape, na, masked):
+    """VERDICT r5 item 6 (built, measured, kept as the no-room path): kl_tile_kernel with Yinit = NULL accumulates y = sum_q x[q] * row q of
+    the fixed factor in its prologue instead of reading the wh_store GEMM's matrix-sized buffer.  Both orientations: a first iteration with
+    room leaves the transposed copy AT behind (it belongs to the matrix), set_factors with another rank drops What (it belongs to the
+    factors), and with
+    nnlm_debug_alloc_limit What cannot come back -- W and H half-steps then run the tile kernel on its own starting states.  Same factors
+    as the roomy run to fp32 rounding of the starting states, same sweep counts, oracle within the mode's bar."""
+    n, m, k = shape
+    rng, A, W0, H0 = _planted(1300 + method + n, n, m, k)
+    Wm = Hm = None
+    if na:
+        A[rng.random(A.shape) < 0.1] = np.nan
+    if masked:
+        Wm, Hm = rng.random((n, k)) < 0.1, rng.random((k, m)) < 0.1
+        W0, H0 = np.where(Wm, 0.0, W0), np.where(Hm, 0.0, H0)
+    reg = [0.01, 0.005, 0.02]
+    inner = 2 if method == 3 else 1
+
+    def run(limit):
+        with nnlm_amd.Handle(0, _lib.PREC_F32) as h:
+            h.set_matrix(A)
+            h.set_factors(k + 1, np.hstack([W0, W0[:, :1]]), np.vstack([H0, H0[:1]]))
+            h.iterate(1, reg, reg, inner, 1e-9, method)  # (leaves AT behind; another rank: set_factors below drops What with the factors)
+            h.set_factors(k, W0, H0, Wm, Hm)
+            h.take_sweeps()
+            _lib.debug_alloc_limit(limit)
+            try:
+                h.iterate(2, reg, reg, inner, 1e-9, method)
+            finally:
+                _lib.debug_alloc_limit(0)
+            W, H = h.get_factors()
+            return W, H, h.take_sweeps(), (h.get_info("kl_form_w"), h.get_info("kl_form_h"))
+
+    W1, H1, s1, f1 = run(0)
+    W2, H2, s2, f2 = run(1 << 19)
+    assert f1 == (0, 0) and f2 == (1, 1), (f1, f2)  # (the own-init form did run, in both orientations)
+    # (the prologue's fused multiply-adds take the coordinates in the GEMM's order: at small ranks the states are bit-identical)
+    assert relF(W2, W1) < 5e-6 and relF(H2, H1) < 5e-6, (relF(W2, W1), relF(H2, H1))
+    assert s1 == s2
+    o = ref.c_nnmf(A, k, W0, H0, Wm, Hm, reg, reg, 2, -1.0, 0, 0, False, inner, 1e-9, method, 2)
+    assert relF(W2, o["W"]) < 1e-4 and relF(H2, o["H"]) < 1e-4, (relF(W2, o["W"]), relF(H2, o["H"]))
 
 
 @pytest.mark.parametrize("n,m,k", [(200, 100, 5), (255, 128, 5), (256, 127, 5), (129, 128, 5), (300, 190, 20), (513, 130, 40), (777, 333, 50)])
