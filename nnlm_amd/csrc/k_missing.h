@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void colsolve_ls_kernel(const SweepArgs a, siz
             const int q = 8 * c + e;
             double v = 0.0;
             if (q < k && lv) {
-                v = G[(size_t)q * a.KPg + lane];
+                v = G[(a.g_upper && q > lane) ? (size_t)lane * a.KPg + q : (size_t)q * a.KPg + lane];
                 if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1; // :98-99
                 if (a.r1 != 0) v += a.r1;                          // :100-101
                 if (q == lane) v += NNLM_TINY;                     // :103
@@ -238,7 +238,7 @@ __device__ static inline double na_fma(double a, double b, double c) { return __
 template <typename T, int NT, bool TAIL>
 __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
                                                           const T *__restrict__ Yrow, const double *__restrict__ Gfull, double *__restrict__ Gcols,
-                                                          int ncols, int col0, int k)
+                                                          int ncols, int col0, int k, int upper_only)
 {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
         }
     }
     double *out = Gcols + (size_t)col * KP * KP;
-    auto put = [&](int i, int j, double sum) { // both triangles
+    auto put = [&](int i, int j, double sum) { // both triangles, or (upper_only: the solvers read G[min][max]) the upper one
         const double v = complement ? Gfull[i * KP + j] - sum : sum;
-        out[i * KP + j] = v;
-        if (i != j) out[j * KP + i] = v;
+        if (!upper_only || i <= j) out[i * KP + j] = v;
+        if (i != j && (!upper_only || j < i)) out[j * KP + i] = v;
     };
     int pi = 0;
 #pragma unroll
@@ -415,9 +415,9 @@ __global__ __launch_bounds__(256) void na_gram_lds_kernel(const uint32_t *__rest
                 double sum = (double)acc[pi][r];
                 if (F32) sum += acc64[F32 ? pi : 0][r];
                 const double v = complement ? Gfull[i * KP + j] - sum : sum;
-                if (TAIL || (i < k && j < k)) { // (entries beyond k are never read by the solvers)
+                if ((TAIL || (i < k && j < k)) && !(upper_only && i > j)) { // (entries beyond k are never read by the solvers)
                     out[i * KP + j] = v;
-                    if (a != b) out[j * KP + i] = v;
+                    if (a != b && !upper_only) out[j * KP + i] = v;
                 }
             }
     if (TAIL) {
@@ -473,7 +473,7 @@ typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
 template <int NKQ>
 __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ meta, const int *__restrict__ idx,
                                                           const uint32_t *__restrict__ Y16rows, int zero_row, const int *__restrict__ exp_in,
-                                                          const double *__restrict__ Gfull, double *__restrict__ Gcols, int ncols, int col0, int k)
+                                                          const double *__restrict__ Gfull, double *__restrict__ Gcols, int ncols, int col0, int k, int upper_only)
 {
     constexpr int KP = 16 * NKQ;          // row stride of Gfull / Gcols
     constexpr int NP = NKQ * (NKQ + 1) / 2;
@@ -595,11 +595,13 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * a + 4 * lg + r, j = 16 * b + l15; // C/D layout of the 16x16 fp32 tile: row 4 (lane >> 4) + r, column lane & 15
-                if (i < k && j < k) {                                // (entries beyond k are never read by the solvers)
+                // (entries beyond k are never read by the solvers; upper_only -- colsolve_f32_kernel reads G[min][max] --: nothing below the
+                //  diagonal is written: the mirrored tiles were 8-byte stores 512 bytes apart, 2.4 % of a config-5 iteration)
+                if (i < k && j < k && !(upper_only && i > j)) {
                     const double sum = (acc64[pi][r] + (double)accm[pi][r] + (double)accx[pi][r] * (1.0 / 2048.0)) * unscale;
                     const double v = complement ? Gfull[i * KP + j] - sum : sum;
                     out[i * KP + j] = v;
-                    if (a != b) out[j * KP + i] = v;
+                    if (a != b && !upper_only) out[j * KP + i] = v;
                 }
             }
 }
@@ -654,7 +656,9 @@ __global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, si
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int q = q0 + e;
-            gv[e] = (q < KR && q < k && lv) ? G[(size_t)q * a.KPg + lane] : 0.0;
+            // (g_upper: the per-column Gram holds its upper triangle only -- row `lane` of the symmetric matrix is column `lane` down to the
+            //  diagonal, then row `lane`)
+            gv[e] = (q < KR && q < k && lv) ? G[(a.g_upper && q > lane) ? (size_t)lane * a.KPg + q : (size_t)q * a.KPg + lane] : 0.0;
         }
 #pragma unroll
         for (int e = 0; e < 16; e++) {
@@ -683,20 +687,24 @@ __global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, si
         const float tol = (float)a.rel_tol, tole = tol * (float)NNLM_TINY;
         bool more = true; // rel = 1 + rel_tol > rel_tol
         for (; t < a.max_iter && more; t++) {
-            // a step:   s_mov_b64 exec = {q};  v_max_f32 xd = max(-x, -nu);  v_add_f32 x += xd;  s_mov_b64 exec = all;
-            //           v_readlane_b32 d = xd[q];  v_fma_f32 nu += d * Gs[q]
-            // xd is ONE register through the sweep: a coordinate moves once per sweep, so at its end lane q still holds the delta of ITS step
+            // a step:   v_min_f32 t = min(x, nu) (every lane: lane q's entry is MINUS the step's delta);  v_readlane_b32 e = t[q];
+            //           v_writelane_b32 xd[q] = e;  v_fma_f32 nu -= e * Gs[q]        -- four vector instructions, NO scalar ones.
+            // A coordinate moves once per sweep: lane q's x is still the sweep's starting value at ITS step, so x is brought up to date once,
+            // behind the sweep (x = x0 - xd), and xd is ONE register through the sweep.  (Until round 6 the step switched the execution mask to
+            // lane q around v_max / v_add: three to five s_mov per step on the ONE scalar unit the CU's four SIMDs share -- at eight
+            // wavefronts per SIMD as much scalar as vector issue time.  Same values to the last bit.)
             const float x0 = x;
             float xd = 0.0f;
             int kk = k;
             asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
             auto step = [&](const int q) {
-                unsigned long long sv;
-                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %4\n\tv_max_f32 %0, -%1, -%3\n\tv_add_f32 %1, %1, %0\n\ts_mov_b64 exec, %2"
-                             : "+v"(xd), "+v"(x), "=&s"(sv)
-                             : "v"(nu), "s"(1ull << q));
-                const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xd), q));
-                nu = __builtin_fmaf(d, gs[q], nu);
+                // (v_min, v_readlane and v_fma are the compiler's: it knows their wait states -- a vector result read by v_readlane, a scalar
+                //  written by a vector instruction read by the next one: two on gfx940+.  v_writelane has no builtin in this toolchain; written
+                //  out BEHIND the fused multiply-add -- tied to its result --, so that those wait states have passed for it too)
+                const float tq = __builtin_fminf(x0, nu); // e = -delta = min(x, nu)  (max(x - nu, 0) - x = -min(x, nu))
+                const int ei = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tq), q);
+                nu = __builtin_fmaf(-__builtin_bit_cast(float, ei), gs[q], nu);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(xd) : "s"(ei), "n"(q), "v"(nu)); // (nu: an input only -- as an output the compiler canonicalises it before the next v_min)
             };
 #pragma unroll
             for (int c = 0; c < NKQ; c++) {
@@ -710,6 +718,7 @@ __global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, si
                             if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
                 }
             }
+            x = x0 - xd;
             const bool big = 2.0f * __builtin_fabsf(xd) > __builtin_fmaf(tol, x + x0, tole); // src/base_algorithms.cpp:29-32 without the division
             more = __ballot(big && lv) != 0ull || 0.0f > tol;
         }
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(256) void colsolve_strict_kernel(const SweepArgs a,
     for (int q = 0; q < KR; q++) {
         double v = 0.0;
         if (q < k && lv) {
-            v = G[(size_t)q * a.KPg + lane];
+            v = G[(a.g_upper && q > lane) ? (size_t)lane * a.KPg + q : (size_t)q * a.KPg + lane];
             if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
             if (a.r1 != 0) v += a.r1;
             if (q == lane) v += NNLM_TINY;

@@ -59,6 +59,7 @@ struct SweepArgs {
     // k_sweep_q.h only (NULL elsewhere): what the NEXT half-step needs from the factor solved here, produced from the
     // final x image while it is still in LDS -- its Gram partial sums and max|x| (the scale of its split-fp16 copy)
     unsigned *maxbits = nullptr;      // atomicMax of the float bit pattern of max|x| over the solved columns
+    int g_upper = 0;                  // colsolve_*_kernel: the per-column Grams at Graw hold their upper triangle only (na_gram_*_kernel, upper_only)
     double *gram_slabs = nullptr;     // [workgroups][KP*KP]  Gram of each workgroup's 64 (persistent form: 16 G) columns (upper tiles)
 };
 

@@ -1637,7 +1637,7 @@ static size_t yrow_bytes(const nnlm_handle *h)
 }
 
 // Per-column Grams of columns [c0, c1) (row lists exist for all ncols columns)
-static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols, int c0, int c1)
+static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int words, int p, int ncols, int c0, int c1, bool upper_only = false)
 {
     const int nc = c1 - c0;
     if (nc <= 0) return NNLM_OK;
@@ -1651,7 +1651,7 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
         // [p + 64 rows][64 hi | 64 lo halves]; rows p .. are zero (the kernel's "no row" index)
         factor16c_kernel<<<p / 64 + 1, 256, 0, h->stream>>>(Ym, ldy, p, h->k, h->fixed_maxw ? h->fixed_maxw : h->maxbits, h->scal_exp + 3, (uint32_t *)h->Yrow);
         const int nb = (nc + 3) / 4;
-#define NNLM_NAGH(N_) na_gram_f16_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const uint32_t *)h->Yrow, p, h->scal_exp + 3, h->Graw, h->Gcols, c1, c0, h->k)
+#define NNLM_NAGH(N_) na_gram_f16_kernel<N_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const uint32_t *)h->Yrow, p, h->scal_exp + 3, h->Graw, h->Gcols, c1, c0, h->k, upper_only ? 1 : 0)
         switch (h->NKQ) {
         case 1: NNLM_NAGH(1); break;
         case 2: NNLM_NAGH(2); break;
@@ -1671,7 +1671,7 @@ static int launch_na_gram(nnlm_handle *h, int which, const uint32_t *bits, int w
     const int nb = (nc + 3) / 4;
     const int ntail = h->k - 16 * (h->NKQ - 1);
     const bool tl = h->NKQ >= 2 && (ntail == 1 || ntail == 2);
-#define NNLM_NAGL(N_, TL_) na_gram_lds_kernel<double, N_, TL_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const double *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k)
+#define NNLM_NAGL(N_, TL_) na_gram_lds_kernel<double, N_, TL_><<<nb, 256, 0, h->stream>>>(h->na_ptr[which], h->na_meta[which], h->na_idx[which], (const double *)h->Yrow, h->Graw, h->Gcols, c1, c0, h->k, upper_only ? 1 : 0)
     switch (h->NKQ) {
     case 1: NNLM_NAGL(1, false); break;
     case 2: if (tl) NNLM_NAGL(1, true); else NNLM_NAGL(2, false); break;
@@ -2378,10 +2378,11 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             // per-column Gram over the finite rows of each column (src/update_with_missing.cpp:90), then the solver
             const int p_len = (which == 1) ? h->n : h->m;
             {
-                int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, ncols, a.col0, a.ncols);
+                int rcg = launch_na_gram(h, which, which == 1 ? h->miss : h->missT, (which == 1 ? h->npad : h->mpad) / 32, p_len, ncols, a.col0, a.ncols, !generic_rank(h));
                 if (rcg != NNLM_OK) return rcg;
             }
             a.Graw = h->Gcols;
+            a.g_upper = generic_rank(h) ? 0 : 1; // (what launch_na_gram was told to write: ranks <= 64 keep the upper triangle only)
             if (generic_rank(h)) {
                 int rcs = launch_sweep_generic(h, method, a, (size_t)h->KP * h->KP);
                 if (rcs != NNLM_OK) return rcs;
