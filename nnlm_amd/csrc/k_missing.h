@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 // registers of Gram row, 4 wavefronts per SIMD -- 0.33 / 0.66 ms per half-step at config 5).  Round 6 (the mode's contract is 1e-4 on
 // W, H; k_sweep_f.h): the chain on fp32 state.  The starting gradient nu0 = (G x - c + L1) / diag is still formed in fp64 (that is where the cancellation is) WHILE
 // the scaled Gram row is read, so no fp64 copy of the row is ever held; the row lives in KR fp32 registers (52 instead of 104 at k = 50:
-// 8 wavefronts per SIMD instead of 4); a step is four vector instructions instead of five (one v_readlane_b32), all of them fp32 (2.9
+// 5 wavefronts per SIMD instead of 4); a step is four vector instructions instead of five (one v_readlane_b32), all of them fp32 (2.9
 // against 5.1 cycles per instruction and SIMD, scripts/exp/valu_exp.hip).
 template <int NKQ, bool HAS_MASK, int KR = 16 * NKQ>
 __global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, size_t g_stride)
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, si
             //           v_writelane_b32 xd[q] = e;  v_fma_f32 nu -= e * Gs[q]        -- four vector instructions, NO scalar ones.
             // A coordinate moves once per sweep: lane q's x is still the sweep's starting value at ITS step, so x is brought up to date once,
             // behind the sweep (x = x0 - xd), and xd is ONE register through the sweep.  (Until round 6 the step switched the execution mask to
-            // lane q around v_max / v_add: three to five s_mov per step on the ONE scalar unit the CU's four SIMDs share -- at eight
+            // lane q around v_max / v_add: three to five s_mov per step on the ONE scalar unit the CU's four SIMDs share -- at five
             // wavefronts per SIMD as much scalar as vector issue time.  Same values to the last bit.)
             const float x0 = x;
             float xd = 0.0f;
