@@ -167,7 +167,7 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
                 # (which form the launch took is the library's decision -- device CU count, LDS limit: nnlm_get_info, recorded by the caller)
                 form = (sweep_forms or {}).get(nm)
                 sweep_kernel = {1: "sweep_scd_qw_kernel", 2: "sweep_scd_f_kernel"}.get(form, "sweep_scd_q_kernel")
-                knm = ("na_gram_f16_kernel + colsolve_f32_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
+                knm = ("na_gram_f16_kernel + colsolve_row_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
                         "flops = inner*cols*k*(2k+8); a SIMD runs one 16-column wavefront at full speed, so the floor of a launch is "

@@ -12,8 +12,9 @@
 //     finite rows or  G_full - sum over missing rows  (complement), whichever touches fewer rows, from row lists made once per
 //     matrix: na_gram_f16_kernel (fp32-operand mode: split-fp16 rows, v_mfma_f32_16x16x32_f16) / na_gram_lds_kernel<double>
 //     (strict mode: fp64 rows gathered by LDS-DMA, v_mfma_f64_16x16x4_f64);
-//   * one wavefront per column, lane = coordinate, solves with that column's own G: colsolve_f32_kernel (SCD, fp32-operand
-//     mode: rows of G divided by their diagonal), colsolve_strict_kernel (SCD in the reference's arithmetic), colsolve_ls_kernel
+//   * solves with that column's own G: colsolve_row_kernel (k_colsolve_row.h: SCD of the fp32-operand mode, four columns per wavefront,
+//     rows of G divided by their diagonal); one wavefront per column, lane = coordinate: colsolve_strict_kernel (SCD in the reference's
+//     arithmetic), colsolve_ls_kernel
 //     (Lee's multiplicative updates: lane r keeps column r of G_j in VGPRs, G[q][r] is an indirect VGPR read, x[q] a v_readlane).
 //
 // The missing-entry index sets are 1-bit-per-entry masks built by the prep pass (exact, integer):
@@ -591,152 +592,30 @@ __global__ __launch_bounds__(256) void na_gram_f16_kernel(const uint32_t *__rest
 #pragma unroll
     for (int a = 0; a < NKQ; a++)
 #pragma unroll
-        for (int b = a; b < NKQ; b++, pi++)
+        for (int b = a; b < NKQ; b++, pi++) {
+            // C/D layout of the 16x16 fp32 tile: row i = 16 a + 4 (lane >> 4) + r, column j = 16 b + (lane & 15)
+            const int i0 = 16 * a + 4 * lg, j = 16 * b + l15;
+            f64x4 v4;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = 16 * a + 4 * lg + r, j = 16 * b + l15; // C/D layout of the 16x16 fp32 tile: row 4 (lane >> 4) + r, column lane & 15
-                // (entries beyond k are never read by the solvers; upper_only -- colsolve_f32_kernel reads G[min][max] --: nothing below the
-                //  diagonal is written: the mirrored tiles were 8-byte stores 512 bytes apart, 2.4 % of a config-5 iteration)
-                if (i < k && j < k && !(upper_only && i > j)) {
-                    const double sum = (acc64[pi][r] + (double)accm[pi][r] + (double)accx[pi][r] * (1.0 / 2048.0)) * unscale;
-                    const double v = complement ? Gfull[i * KP + j] - sum : sum;
-                    out[i * KP + j] = v;
-                    if (a != b && !upper_only) out[j * KP + i] = v;
-                }
+                const double sum = (acc64[pi][r] + (double)accm[pi][r] + (double)accx[pi][r] * (1.0 / 2048.0)) * unscale;
+                v4[r] = complement ? Gfull[(i0 + r) * KP + j] - sum : sum;
             }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// colsolve_f32_kernel -- SCD-LS with a Gram of its own per column (or one shared Gram), fp32-operand mode (k <= 64).
-//
-// colsolve_ls_kernel above spends ~15 fp64 instructions per coordinate (four v_readlane pairs, reciprocal + Markstein quotient, compare,
-// select): 2.9 ms per half-step at config 5.  This kernel runs the same recurrence in the arithmetic of the fp32-operand mode (rows of G
-// divided by their diagonal, nu = mu / G[q][q], d = max(-x, -nu): ONE instruction) with one wavefront per column, lane = coordinate;
-// lane q alone takes its coordinate's step under an execution mask of one lane, the delta reaches every lane's gradient through an SGPR.
-// Rounds 2-5 ran the chain in fp64 (colsolve_fast_kernel, scripts/exp/csrc_r5/k_missing.h: five vector instructions per step, 104
-// registers of Gram row, 4 wavefronts per SIMD -- 0.33 / 0.66 ms per half-step at config 5).  Round 6 (the mode's contract is 1e-4 on
-// W, H; k_sweep_f.h): the chain on fp32 state.  The starting gradient nu0 = (G x - c + L1) / diag is still formed in fp64 (that is where the cancellation is) WHILE
-// the scaled Gram row is read, so no fp64 copy of the row is ever held; the row lives in KR fp32 registers (52 instead of 104 at k = 50:
-// 5 wavefronts per SIMD instead of 4); a step is four vector instructions instead of five (one v_readlane_b32), all of them fp32 (2.9
-// against 5.1 cycles per instruction and SIMD, scripts/exp/valu_exp.hip).
-template <int NKQ, bool HAS_MASK, int KR = 16 * NKQ>
-__global__ __launch_bounds__(256) void colsolve_f32_kernel(const SweepArgs a, size_t g_stride)
-{
-    const int lane = threadIdx.x & 63;
-    const int col = a.col0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (col >= a.ncols) return; // whole wavefront
-    const int k = a.k;
-    const bool lv = lane < k;
-    const int lq = lv ? lane : 0;
-    const double *G = a.Graw + (size_t)col * g_stride;
-    unsigned long long mword = 0ull;
-    if (HAS_MASK) mword = a.mask[col];
-    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-    const bool skip = HAS_MASK && ((mword & kmask) == kmask); // arma::all(mask.col(j)), src/update_with_missing.cpp:75-76
-
-    double gd = 1.0; // edited G[lane][lane] (src/update_with_missing.cpp:98-103)
-    if (lv) {
-        gd = G[(size_t)lq * a.KPg + lq];
-        if (a.r0 != a.r1) gd += a.r0 - a.r1;
-        if (a.r1 != 0) gd += a.r1;
-        gd += NNLM_TINY;
-    }
-    const double rgd = 1.0 / gd;
-    const double x64 = lv ? a.X[(size_t)lq * a.ldx + col] : 0.0;
-    double cv = 0.0;
-    if (lv)
-        for (int s = 0; s < a.nslabs; s++) cv += a.Cx[(size_t)s * a.slab_stride + (size_t)lq * a.ldc + col];
-    // nu = (G x - c + L1) / G[lane][lane] in fp64, row `lane` of the scaled Gram (G is symmetric: G[lane][q] = G[q][lane], a coalesced read)
-    // kept in fp32
-    double nu64 = lv ? (((a.r2 != 0) ? a.r2 - cv : -cv) * rgd) : 0.0;
-    float gs[KR];
+            // upper_only (the one-column-per-wavefront solvers read G[min][max]): nothing below the diagonal is written.  Otherwise
+            // (colsolve_row_kernel reads whole rows) the mirrored tile goes out as ONE 32-byte store per lane -- the lane's four rows i are
+            // four consecutive entries of row j, the four lane groups fill a 128-byte line -- not as four 8-byte stores 512 bytes apart
+            // (those were 2.4 % of a config-5 iteration).  Entries beyond k are never read by the solvers (the buffer has KP x KP of them).
 #pragma unroll
-    for (int q0 = 0; q0 < KR; q0 += 16) { // (16 fp64 loads in flight at a time: all KR at once would be the kernel's register peak)
-        double gv[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int q = q0 + e;
-            // (g_upper: the per-column Gram holds its upper triangle only -- row `lane` of the symmetric matrix is column `lane` down to the
-            //  diagonal, then row `lane`)
-            gv[e] = (q < KR && q < k && lv) ? G[(a.g_upper && q > lane) ? (size_t)lane * a.KPg + q : (size_t)q * a.KPg + lane] : 0.0;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int q = q0 + e;
-            if (q < KR) {
-                double v = 0.0;
-                if (q < k && lv) {
-                    v = gv[e];
-                    if (q == lane && a.r0 != a.r1) v += a.r0 - a.r1;
-                    if (a.r1 != 0) v += a.r1;
-                    if (q == lane) v += NNLM_TINY;
-                    v *= rgd;
-                }
-                float g32 = (float)v;
-                asm volatile("" : "+v"(g32)); // (a register of its own: left to the allocator, the 52 floats sit in the low halves of 52 register PAIRS)
-                gs[q] = g32;
-                if (q < k) nu64 = __builtin_fma(readlane_f64(x64, q), v, nu64);
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + r;
+                if (i < k && j < k && !(upper_only && i > j)) out[i * KP + j] = v4[r];
             }
+            if (a != b && !upper_only && j < k) *(f64x4 *)(out + j * KP + i0) = v4;
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float x = (float)x64, nu = (float)nu64;
-
-    unsigned t = 0;
-    if (!skip) {
-        const float tol = (float)a.rel_tol, tole = tol * (float)NNLM_TINY;
-        bool more = true; // rel = 1 + rel_tol > rel_tol
-        for (; t < a.max_iter && more; t++) {
-            // a step:   v_min_f32 t = min(x, nu) (every lane: lane q's entry is MINUS the step's delta);  v_readlane_b32 e = t[q];
-            //           v_writelane_b32 xd[q] = e;  v_fma_f32 nu -= e * Gs[q]        -- four vector instructions, NO scalar ones.
-            // A coordinate moves once per sweep: lane q's x is still the sweep's starting value at ITS step, so x is brought up to date once,
-            // behind the sweep (x = x0 - xd), and xd is ONE register through the sweep.  (Until round 6 the step switched the execution mask to
-            // lane q around v_max / v_add: three to five s_mov per step on the ONE scalar unit the CU's four SIMDs share -- at five
-            // wavefronts per SIMD as much scalar as vector issue time.  Same values to the last bit.)
-            const float x0 = x;
-            float xd = 0.0f;
-            int kk = k;
-            asm volatile("" : "+s"(kk)); // (opaque per sweep: otherwise 64 hoisted "q < k" masks spill into VGPR lanes)
-            auto step = [&](const int q) {
-                // (v_min, v_readlane and v_fma are the compiler's: it knows their wait states -- a vector result read by v_readlane, a scalar
-                //  written by a vector instruction read by the next one: two on gfx940+.  v_writelane has no builtin in this toolchain; written
-                //  out BEHIND the fused multiply-add -- tied to its result --, so that those wait states have passed for it too)
-                const float tq = __builtin_fminf(x0, nu); // e = -delta = min(x, nu)  (max(x - nu, 0) - x = -min(x, nu))
-                const int ei = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tq), q);
-                nu = __builtin_fmaf(-__builtin_bit_cast(float, ei), gs[q], nu);
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(xd) : "s"(ei), "n"(q), "v"(nu)); // (nu: an input only -- as an output the compiler canonicalises it before the next v_min)
-            };
-#pragma unroll
-            for (int c = 0; c < NKQ; c++) {
-                if (!HAS_MASK && 16 * c + 16 <= KR && 16 * c + 16 <= kk) { // a whole block of 16 coordinates: no per-step test
-#pragma unroll
-                    for (int e = 0; e < 16; e++) step(16 * c + e);
-                } else if (16 * c < kk) {
-#pragma unroll
-                    for (int e = 0; e < 16; e++)
-                        if (16 * c + e < KR) // (compile time)
-                            if (16 * c + e < kk && !(HAS_MASK && ((mword >> (16 * c + e)) & 1ull))) step(16 * c + e); // wave-uniform
-                }
-            }
-            x = x0 - xd;
-            const bool big = 2.0f * __builtin_fabsf(xd) > __builtin_fmaf(tol, x + x0, tole); // src/base_algorithms.cpp:29-32 without the division
-            more = __ballot(big && lv) != 0ull || 0.0f > tol;
-        }
-    }
-    if (lv) {
-        // (masked coordinates never took a step: their fp32 copy equals the rounded input -- hand the fp64 input back unchanged)
-        const double xo = (HAS_MASK && ((mword >> lane) & 1ull)) || skip ? x64 : (double)x;
-        a.Xout[(size_t)lane * a.ldo + (col - a.ocol0)] = xo;
-        if (a.op_mode == 1) {
-            if (a.op_f64) ((double *)a.op)[(size_t)lane * a.op_ld + col] = xo;
-            else ((float *)a.op)[(size_t)lane * a.op_ld + col] = (float)xo;
-        }
-    }
-    if (lane == 0 && t) atomicAdd(a.sweeps, (unsigned long long)t);
 }
 
 // colsolve_strict_kernel -- SCD-LS per column in the REFERENCE's arithmetic (strict fp64 mode) with the structure of
-// colsolve_f32_kernel: one wavefront per column, lane = coordinate, row `lane` of the edited Gram in registers, the coordinate loop
+// the fp32-operand mode's former solver: one wavefront per column, lane = coordinate, row `lane` of the edited Gram in registers, the coordinate loop
 // fully unrolled.  Every lane evaluates the step of ITS coordinate from its own x, mu, G[lane][lane] -- tmp = max(x - mu / G, 0) with
 // the correctly rounded quotient (reciprocal + Markstein correction, k_sweep.h), d = tmp - x -- and lane q's d is the step's delta:
 // 2 v_readlane_b32 + 1 v_fma_f64 bring mu up to date (d = 0 when the reference skips the coordinate: adds nothing).  Lane q keeps

@@ -1526,35 +1526,10 @@ static void launch_colsolve_m(const SweepArgs &a, size_t g_stride, hipStream_t s
     colsolve_ls_kernel<NKQ, 2><<<nb, 256, 0, s>>>(a, g_stride);
 }
 
-// F32 mode, SCD: colsolve_f32_kernel (scaled rows of G in fp32 registers, four fp32 vector instructions per coordinate; its fp64-chain
-// predecessor colsolve_fast_kernel: scripts/exp/csrc_r5/k_missing.h)
-template <int NKQ>
-static void launch_colsolve_fast_m(const SweepArgs &a, size_t g_stride, hipStream_t s)
-{
-    const int nb = (a.ncols - a.col0 + 3) / 4;
-    if (nb <= 0) return;
-    constexpr int KS = NKQ > 1 ? 16 * (NKQ - 1) + 4 : 16; // k = 16 j + 1 .. 16 j + 4: a Gram row of 16 j + 4 registers (k = 50: 52)
-    if (NKQ > 1 && a.k <= KS) {
-        if (a.mask) colsolve_f32_kernel<NKQ, true, KS><<<nb, 256, 0, s>>>(a, g_stride);
-        else colsolve_f32_kernel<NKQ, false, KS><<<nb, 256, 0, s>>>(a, g_stride);
-        return;
-    }
-    if (a.mask) colsolve_f32_kernel<NKQ, true><<<nb, 256, 0, s>>>(a, g_stride);
-    else colsolve_f32_kernel<NKQ, false><<<nb, 256, 0, s>>>(a, g_stride);
-}
+// F32 mode, SCD: colsolve_row_kernel (k_colsolve_row.h, tu_colsolve.hip): four columns per wavefront, the step's delta by DPP row broadcast
 static bool colsolve_fast_ok(const nnlm_handle *h, int method)
 {
     return method == 1 && h->prec == NNLM_PREC_F32 && h->k <= NNLM_KQ_MAX;
-}
-
-static void launch_colsolve_fast(nnlm_handle *h, const SweepArgs &a, size_t g_stride)
-{
-    switch (h->NKQ) {
-    case 1: launch_colsolve_fast_m<1>(a, g_stride, h->stream); break;
-    case 2: launch_colsolve_fast_m<2>(a, g_stride, h->stream); break;
-    case 3: launch_colsolve_fast_m<3>(a, g_stride, h->stream); break;
-    default: launch_colsolve_fast_m<4>(a, g_stride, h->stream); break;
-    }
 }
 
 template <int NKQ>
@@ -1574,7 +1549,7 @@ static void launch_colsolve_strict_m(const SweepArgs &a, size_t g_stride, hipStr
 static void launch_colsolve(nnlm_handle *h, int method, const SweepArgs &a, size_t g_stride)
 {
     if (colsolve_fast_ok(h, method)) {
-        launch_colsolve_fast(h, a, g_stride);
+        nnlm_tu_colsolve_row(a, g_stride, h->stream);
         return;
     }
     // SCD in the reference's arithmetic (strict mode): the unrolled lane-local form; Lee's updates: colsolve_lee_kernel

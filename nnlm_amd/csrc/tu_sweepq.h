@@ -11,3 +11,5 @@ hipError_t nnlm_tu_sweep_q(const SweepArgs &a, const double *img, int nb, int NB
 hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int NB, bool strict, int G, hipStream_t st);
 // fp32-operand mode (k_sweep_f.h, tu_sweepf.hip): nb workgroups of NW = 4 or 8 wavefronts of 16 columns; reads a.Graw, no operand image
 hipError_t nnlm_tu_sweep_f(const SweepArgs &a, int nb, int NB, int NW, hipStream_t st);
+// fp32-operand mode, per-column Grams (k_colsolve_row.h, tu_colsolve.hip): columns a.col0 .. a.ncols - 1, four per wavefront
+void nnlm_tu_colsolve_row(const SweepArgs &a, size_t g_stride, hipStream_t st);

@@ -648,7 +648,7 @@ def test_missing_values_per_column_gram_every_tile_form(pname, prec, tol, k):
         h.set_matrix(A)
         h.set_factors(k, W0, H0)
         if pname == "f32":
-            tol = 1e-4  # (round 6: colsolve_f32_kernel runs the chain on fp32 state; cold half-step from random factors, see test_half_step_matches_oracle)
+            tol = 1e-4  # (round 6: the per-column solver runs the chain on fp32 state; cold half-step from random factors, see test_half_step_matches_oracle)
         h.half_step(1, reg, 4, 1e-9, 1)
         _, H1 = h.get_factors()
         s1 = h.take_sweeps()
