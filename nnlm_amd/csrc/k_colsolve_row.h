@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, (KR * CPL > 208) ? 1 : 2) void colsolve_row_ke
 #pragma unroll
                 for (int e = 0; e < QB; e++) {
                     const int q = q0 + e;
-                    const unsigned off = (q > lane) ? offr + (unsigned)q : (unsigned)q * (unsigned)a.KPg + offc;
+                    const unsigned off = (a.g_upper && q > lane) ? offr + (unsigned)q : (unsigned)q * (unsigned)a.KPg + offc;
                     gv[e] = (q < KR && q < k) ? Gc[off] : 0.0;
                 }
 #pragma unroll
