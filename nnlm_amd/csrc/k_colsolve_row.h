@@ -32,24 +32,6 @@ template <int I, int N, class F> __device__ __forceinline__ void csr_for(F &&f)
         csr_for<I + 1, N>(f);
     }
 }
-template <int CTRL> __device__ __forceinline__ float csr_bcast(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL> __device__ __forceinline__ double csr_bcast64(double v)
-{
-    int2 p = __builtin_bit_cast(int2, v);
-    p.x = __builtin_amdgcn_update_dpp(0, p.x, CTRL, 0xF, 0xF, false);
-    p.y = __builtin_amdgcn_update_dpp(0, p.y, CTRL, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, p);
-}
-__device__ static inline double csr_readlane_f64(double v, int src)
-{
-    int2 p = __builtin_bit_cast(int2, v);
-    p.x = __builtin_amdgcn_readlane(p.x, src);
-    p.y = __builtin_amdgcn_readlane(p.y, src);
-    return __builtin_bit_cast(double, p);
-}
 #define CSR_NEWBCAST 0x150 // DPP control row_newbcast:0 (+ L)
 template <int CPL, bool HAS_MASK, int KR>
 __global__ __launch_bounds__(256, (KR * CPL > 208) ? 1 : 2) void colsolve_row_kernel(const SweepArgs a, size_t g_stride)
