@@ -630,7 +630,8 @@ __device__ static inline float kl_wave_total(float v)
 __host__ __device__ static inline int kl_tile_p4(int p) { return ((p + 3) / 4 + 63) / 64 * 64; }
 __host__ __device__ static inline size_t kl_tile_lds_bytes(int p, int k, int C, int mw_masked = 0, int nbuf = 2, int nw = 8)
 {
-    return nbuf * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * (nw > 8 ? nw : 8) * 4 + (size_t)C * mw_masked * 8;
+    return nbuf * (size_t)kl_tile_p4(p) * 16 + (size_t)2 * C * k * 8 + 2 * 2 * C * (nw > 8 ? nw : 8) * 4 + (size_t)C * mw_masked * 8 +
+           (nbuf == 1 ? (size_t)64 * nw * 4 : 0); // (one row buffer: + the per-thread sweep counters)
 }
 // s_waitcnt vmcnt(n), n wave-uniform at run time (0 .. 19: the pieces of a row a wavefront may have in flight)
 __device__ static inline void klt_wait_vm(int n)
@@ -801,6 +802,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
     double S_l = 0.0;
     for (int q = 0; q < k; q++) S_l += xs[lc * k + q];
     unsigned tdone_l = 0;
+    // (SCD only: in Lee's instantiation the same change moved a chunk of the state into scratch INSIDE the step loop -- it keeps its
+    //  20 bytes of per-sweep spills)
+    constexpr bool TDLDS = ONEBUF && METHOD == 3;
+    unsigned *tdl = (unsigned *)(mks + (a.mask ? C * a.mw : 0)); // ONEBUF: [NT] sweep counters (kl_tile_lds_bytes reserves them)
+    auto tid_fresh = [&]() -> int { // threadIdx.x from the lane count and the (scalar) wavefront number
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        return TDLDS ? 64 * wave + ln : tid;
+    };
+    if constexpr (TDLDS) tdl[tid] = 0u;
     bool run_l = live_l && a.max_iter > 0 && (1.0 + a.rel_tol) > a.rel_tol, flag_l = false;
     bool any = (__ballot(run_l) & cmask) != 0ull;
     int par = 0;
@@ -1006,7 +1017,17 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
             KLT_T(6);
         }
         KLT_BARRIER(); // xs[] written by thread 0 during this sweep is read by everyone in the next
-        if (run_l) {
+        if constexpr (TDLDS) {
+            // (160 state registers: the sweep counter -- touched once per sweep -- lives in LDS, not in a register the allocator would park
+            //  in scratch; each lane its own word of the reduction scratch's tail)
+            const int tq = tid_fresh(); // (the thread index rebuilt from the lane count: its address in LDS is not kept through the sweep either)
+            unsigned td = tdl[tq];
+            if (run_l) {
+                td++;
+                run_l = td < a.max_iter && flag_l;
+            }
+            tdl[tq] = td;
+        } else if (run_l) {
             tdone_l++;
             run_l = tdone_l < a.max_iter && flag_l;
         }
@@ -1014,7 +1035,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the row requested for a sweep that did not follow
     __syncthreads();
-    for (int e = tid; e < C * k; e += NT) {
+    const int tid_e = tid_fresh();
+    if constexpr (TDLDS) tdone_l = tdl[tid_e];
+    for (int e = tid_e; e < C * k; e += NT) {
         const int c = e / k, q = e - c * k, col = col0 + c;
         if (col < a.ncols) {
             const double xv = xs[e];
@@ -1022,9 +1045,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : (NT == 1024 ? 4 : 1))) void kl
             if (a.op_mode == 1) ((float *)a.op)[(size_t)q * a.op_ld + col] = (float)xv;
         }
     }
-    if (wave == 0) {
-        const long long tot = wave_sum_ll((lane < C) ? (long long)tdone_l : 0ll);
-        if (lane == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
+    if (tid_e < 64) { // (wavefront 0; the thread index afresh: its copies in `tid`, `lane` need not survive the sweeps)
+        const long long tot = wave_sum_ll((tid_e < C) ? (long long)tdone_l : 0ll);
+        if (tid_e == 0 && tot) atomicAdd(a.sweeps, (unsigned long long)tot);
     }
 #if KLT_TIMING
     KLT_T(7);
