@@ -166,13 +166,19 @@ def analyse(cfg, config_id, kern, n, m, k, s, world, sweep_forms=None):
                 #  the launch takes the persistent form sweep_scd_qw_kernel: 5 .. 7 column groups per CU shared by the wrap-around rule)
                 # (which form the launch took is the library's decision -- device CU count, LDS limit: nnlm_get_info, recorded by the caller)
                 form = (sweep_forms or {}).get(nm)
-                sweep_kernel = {1: "sweep_scd_qw_kernel", 2: "sweep_scd_f_kernel"}.get(form, "sweep_scd_q_kernel")
+                sweep_kernel = {1: "sweep_scd_qw_kernel", 2: "sweep_scd_f_kernel", 3: "sweep_row_kernel"}.get(form, "sweep_scd_q_kernel")
                 knm = ("na_gram_f16_kernel + colsolve_row_kernel" if s == 4 else "na_gram_lds_kernel + colsolve_strict_kernel") if cfg["na"] else sweep_kernel
                 pk = FP64_PEAK_TF
                 note = ("fp64 MFMA issue (v_mfma_f64_4x4x4, 16.6 cycles each, 16 per block-step of 16 columns) / dependent coordinate steps; "
                         "flops = inner*cols*k*(2k+8); a SIMD runs one 16-column wavefront at full speed, so the floor of a launch is "
                         "max(inner, ceil(groups per CU * inner / 4)) sweeps of ~2.16 us")
-                if form == 2 and not cfg["na"]:
+                if form == 3 and not cfg["na"]:
+                    # row form (k_sweep_r.h): four columns per wavefront, five fp32 vector instructions per step of four columns, DPP row broadcast;
+                    # taken while the launch is one round of its wavefronts (<= 32 columns per CU) -- mid-size problems, multi-GPU shards
+                    pk = 157.3
+                    note = ("fp32 chain, row form (k_sweep_r.h): 5 vector instructions per coordinate step of 4 columns, 12.8 ns per step for a lone wavefront, "
+                            "19.5 ns each for two per SIMD (scripts/exp/lane_exp.hip); flops = inner*cols*k*(2k+8) against the fp32 vector peak for scale")
+                elif form == 2 and not cfg["na"]:
                     # round 6, fp32-operand mode: fp32 chain state, rank-4 updates as three-piece bf16 products on v_mfma_f32_16x16x32_bf16.
                     # Bound: instruction issue of ONE wavefront per SIMD (6.5 cycles per instruction, ~34 per block of 4 coordinates and
                     # 16 columns: scripts/exp/issue_exp.hip, profiles/r06_issue_exp.log) -- reported against the fp32 vector/matrix peak for scale

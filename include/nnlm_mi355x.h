@@ -212,7 +212,8 @@ int nnlm_debug_set_cus(int cus);
 int nnlm_debug_alloc_limit(size_t bytes);
 /* Facts about the handle's last launches, for bench.py's kernel attribution: key = "cus" (compute units the launch policy
  * counts), "sweep_form_w" / "sweep_form_h" (SCD sweep of the last W / H half-step: 0 plain sweep_scd_q_kernel, 1 persistent
- * sweep_scd_qw_kernel -- both strict fp64 --, 2 sweep_scd_f_kernel (fp32-operand mode), -1 none yet), "sweep_groups_w" /
+ * sweep_scd_qw_kernel -- both strict fp64 --, 2 sweep_scd_f_kernel, 3 sweep_row_kernel (fp32-operand mode: 3 while the launch is one
+ * round of four-column wavefronts, at most 32 columns per CU), -1 none yet), "sweep_groups_w" /
  * "sweep_groups_h" (column groups -- form 2: wavefronts -- per workgroup of that launch), "kl_form_w" / "kl_form_h" (KL solver of the
  * last W / H half-step: 0 kl_tile_kernel on the starting states of the wh_store GEMM, 1 kl_tile_kernel forming its own starting states
  * -- no room for the matrix-sized buffer --, 2 kl_reg64_kernel (strict), 3 kl_stream_kernel over column chunks, -1 none yet). */

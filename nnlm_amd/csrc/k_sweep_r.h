@@ -1,5 +1,3 @@
-// EXPERIMENT (round 6, built + measured + not taken: profiles/r06_sweep_row_ab.log).  To rebuild: copy next to nnlm_amd/csrc/*.h, add tu_sweepr.hip (scripts/exp/tu_sweepr.hip),
-// declare nnlm_tu_sweep_r / SWEEPR_KMAX / SWEEPR_WG_COLS in tu_sweepq.h and call it from launch_sweep_f (one Gram slab per 32-column workgroup).
 // k_sweep_r.h -- SCD least-squares sweep of the fp32-operand mode, row form (round 6, last session): the recurrence of scd_ls_update
 // (reference src/base_algorithms.cpp:3-37) for the DENSE half-step (one Gram for all columns) in the shape of colsolve_row_kernel
 // (k_colsolve_row.h): FOUR columns per wavefront, a column is a row of 16 lanes, a lane owns CPL = ceil(k / 16) consecutive coordinates
@@ -8,14 +6,16 @@
 // -- five vector instructions for the steps of four columns, 9.7 ns per step and SIMD at two wavefronts per SIMD
 // (scripts/exp/lane_exp.hip, profiles/r06_lane_exp.log).
 //
-// Why beside k_sweep_f.h (one wavefront per 16 columns, the rank-4 update on the bf16 matrix pipe): that kernel spends 34 instructions
-// per block of 4 coordinates x 16 columns -- 0.53 per column and step against 1.25 here -- but a LONE wavefront issues one instruction per
-// 6.5 cycles, and 625 / 1250 groups of 16 columns leave it alone (H) or paired (W) on a SIMD: 238 cycles per block whatever the other
-// SIMDs do.  The row form has four times as many wavefronts for the same columns, every SIMD holds two of them, and the step has no
-// matrix-instruction latency in its chain: 2500 / 5000 wavefronts x 2500 steps x 9.7 ns over 1024 SIMDs.
-// Set-up per workgroup (8 wavefronts, 32 columns): G' = edited Gram (src/update_with_missing.cpp:20-24) with the rows divided by their
+// When it is taken (launch_sweep_f): while the launch fits ONE round of its wavefronts -- at most two per SIMD, i.e. up to 32 columns per
+// CU (8192 on the whole device).  k_sweep_f.h (one wavefront per 16 columns, the rank-4 update on the bf16 matrix pipe) spends 0.53
+// instructions per column and step against 1.25 here, but its chain is 238 cycles per block of four steps for a lone wavefront whatever
+// the other SIMDs do: ~0.1 ms per launch from 16 columns to 16384.  A lone wavefront of THIS form takes 12.8 ns per step (32 us per 50
+// sweeps of 50 coordinates), a pair 19.5 ns each -- no matrix-instruction latency in the chain.  Beyond one round the form loses: its
+// wavefronts hold 200 registers, a CU holds eight of them, and 20000 columns are three rounds of 49 us chains (0.25 against 0.144 ms,
+// profiles/r06_sweep_row_ab.log).  So: the sweeps of mid-size problems and of every multi-GPU shard of the benchmark (<= 8192 columns).
+// Set-up per workgroup (4 or 8 wavefronts, 16 or 32 columns): G' = edited Gram (src/update_with_missing.cpp:20-24) with the rows divided by their
 // diagonal (diagonal exactly 1), built ONCE in LDS as fp64 [step][coordinate] and as -fp32; per column nu0 = ((L1 - c) + G x) / diag in
-// fp64 in the row layout (x_s by DPP row broadcast), rounded to fp32 once.  Masked coordinates as in k_sweep_f.h (x = 0, nu = +1e30: e = 0
+// fp64 in the row layout (x_s from an LDS image of the wavefront's four columns), rounded to fp32 once.  Masked coordinates as in k_sweep_f.h (x = 0, nu = +1e30: e = 0
 // for good; output = the fp64 input).  Epilogue: sweepq_epilogue (factor outputs, max|x|, Gram partial sums of the workgroup's columns).
 #pragma once
 #include "common.h"
@@ -31,14 +31,13 @@ __device__ __forceinline__ double sweepr_edit(double g, bool diag, double r0, do
     if (diag) g += NNLM_TINY;
     return g;
 }
-#define SWEEPR_NW 8                 // wavefronts per workgroup (two per SIMD)
-#define SWEEPR_COLS (4 * SWEEPR_NW) // columns per workgroup
 
-template <int CPL, bool HAS_MASK, int KR, int NT>
-__global__ __launch_bounds__(64 * SWEEPR_NW) void sweep_row_kernel(const SweepArgs a)
+// NW: wavefronts per workgroup -- 4 (16 columns, one wavefront per SIMD) while the launch has at most one workgroup per CU, 8 (32 columns) beyond
+template <int CPL, bool HAS_MASK, int KR, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void sweep_row_kernel(const SweepArgs a)
 {
     static_assert(KR <= 16 * CPL && KR > 16 * (CPL - 1) && NT == CPL, "CPL = ceil(KR / 16) = rank padding / 16");
-    constexpr int NW = SWEEPR_NW, COLS = SWEEPR_COLS, KP = 16 * NT, XS = KP + 2, THREADS = 64 * NW;
+    constexpr int COLS = 4 * NW, KP = 16 * NT, XS = KP + 2, THREADS = 64 * NW;
     constexpr int G64_BYTES = KR * 64 * 8, XL_BYTES = COLS * XS * 8;
     __shared__ __attribute__((aligned(16))) unsigned char r0_all[G64_BYTES > XL_BYTES ? G64_BYTES : XL_BYTES]; // G' fp64 during the set-up, then the x image
     __shared__ __attribute__((aligned(16))) float img[KR * 64];                                                // -G' fp32 [step][coordinate]

@@ -1320,12 +1320,33 @@ static bool sweep_fast(const nnlm_handle *h) { return h->prec == NNLM_PREC_F32 &
 // fp32-operand mode: the fp32-chain kernel (k_sweep_f.h).  One wavefront per 16 columns; four per workgroup (one per SIMD) while the
 // launch has at most one wavefront per SIMD of the device, eight (two per SIMD, 128 columns per workgroup) beyond -- the instruction
 // streams of two wavefronts interleave where a lone one leaves every second issue slot empty.  Reads a.Graw; no operand image.
+// Gram partial-sum slabs a sweep launch may leave behind: one per workgroup -- 64 columns (k_sweep_q.h), 64 / 128 (k_sweep_f.h), or 16 / 32 in
+// the row form, which is taken for at most one workgroup per CU
+static size_t sg_slab_count(const nnlm_handle *h)
+{
+    const int big = h->n > h->m ? h->n : h->m;
+    const int wide = (big + SWEEPQ_COLS - 1) / SWEEPQ_COLS, row = (big + 15) / 16 < h->cus ? (big + 15) / 16 : h->cus;
+    return (size_t)(wide > row ? wide : row) + 1;
+}
 static void launch_sweep_f(nnlm_handle *h, const SweepArgs &a)
 {
     const int ncols = a.ncols - a.col0, NB = (a.k + 3) / 4;
     h->sweep_wgs = 0;
     h->pack_ready = false;
     if (ncols <= 0) return;
+    // Row form (k_sweep_r.h: four columns per wavefront, no matrix instruction in the chain) while the launch is ONE round of its
+    // wavefronts: workgroups of four wavefronts (one per SIMD) up to one workgroup per CU, of eight (two per SIMD) up to 32 columns per CU.
+    // Mid-size problems and the column shards of a multi-GPU run; beyond (the benchmark's 10000 / 20000 columns on one GPU) the
+    // matrix-pipe kernel below, whose 157 workgroups are one round where the row form's would be two or three.
+    if (a.k <= SWEEPR_KMAX && ncols <= 32 * h->cus) {
+        const int NWr = (ncols <= 16 * h->cus) ? 4 : 8;
+        const int nbr = (ncols + 4 * NWr - 1) / (4 * NWr);
+        h->sweep_wgs = nbr;
+        h->sweep_form[h->cur_which] = 3;
+        h->sweep_groups[h->cur_which] = NWr;
+        nnlm_tu_sweep_r(a, nbr, NWr, h->stream);
+        return;
+    }
     const int ngroups = (ncols + 15) / 16, simds = 4 * h->cus;
     const int NW = ngroups > simds ? 8 : 4;
     const int nb = (ncols + 16 * NW - 1) / (16 * NW);
@@ -2037,8 +2058,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
         const bool fastsw = sweep_fast(h);
         if (fastsw && !h->sg_slabs) {
             const int big = h->n > h->m ? h->n : h->m;
-            const int nwg = (big + SWEEPQ_COLS - 1) / SWEEPQ_COLS;
-            HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)nwg * h->KP * h->KP * 8));
+            HIPCHK(h, hipMalloc(&h->sg_slabs, sg_slab_count(h) * h->KP * h->KP * 8));
         }
         unsigned *smax_w = fastsw ? h->maxbits + 4 + (h->sg_par ^ 1) : nullptr; // this half-step's sweep writes its max here
         h->sg_request = fastsw;
@@ -2116,7 +2136,7 @@ static int half_step(nnlm_handle *h, int which, const double reg[3], unsigned in
     if (sg_strict) {
         if (!h->sg_slabs) {
             const int big = h->n > h->m ? h->n : h->m;
-            HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)((big + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1) * h->KP * h->KP * 8));
+            HIPCHK(h, hipMalloc(&h->sg_slabs, sg_slab_count(h) * h->KP * h->KP * 8));
         }
         h->sg_request = true; // this half-step's sweep leaves its slabs for the next one
     }
@@ -2343,7 +2363,7 @@ static int half_step_solve(nnlm_handle *h, int which, const double reg[3], unsig
             if (h->pack_tail) {
                 if (!h->sg_slabs) {
                     const int big = h->n > h->m ? h->n : h->m;
-                    HIPCHK(h, hipMalloc(&h->sg_slabs, (size_t)((big + SWEEPQ_COLS - 1) / SWEEPQ_COLS + 1) * h->KP * h->KP * 8));
+                    HIPCHK(h, hipMalloc(&h->sg_slabs, sg_slab_count(h) * h->KP * h->KP * 8));
                 }
                 a.gram_slabs = h->sg_slabs; // (one slab per workgroup of sweep_scd_q_kernel; folded behind the packed slab below)
                 a.maxbits = h->x16 ? h->maxbits + 8 : nullptr; // (the sweep's atomicMax; handed to the tail and cleared by gram_fold_tail_kernel)
@@ -2736,7 +2756,7 @@ extern "C" int nnlm_get_info(nnlm_handle *h, const char *key, double *value)
 {
     if (!h || !key || !value) return fail(h, NNLM_ERR_ARG, "nnlm_get_info: NULL argument");
     if (strcmp(key, "cus") == 0) *value = h->cus;
-    else if (strcmp(key, "sweep_form_w") == 0) *value = h->sweep_form[0];
+    else if (strcmp(key, "sweep_form_w") == 0) *value = h->sweep_form[0]; // (0 / 1 strict kernels, 2 k_sweep_f.h, 3 k_sweep_r.h)
     else if (strcmp(key, "sweep_form_h") == 0) *value = h->sweep_form[1];
     else if (strcmp(key, "sweep_groups_w") == 0) *value = h->sweep_groups[0];
     else if (strcmp(key, "sweep_groups_h") == 0) *value = h->sweep_groups[1];

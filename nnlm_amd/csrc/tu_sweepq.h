@@ -13,3 +13,6 @@ hipError_t nnlm_tu_sweep_qw(const SweepArgs &a, const double *img, int nb, int N
 hipError_t nnlm_tu_sweep_f(const SweepArgs &a, int nb, int NB, int NW, hipStream_t st);
 // fp32-operand mode, per-column Grams (k_colsolve_row.h, tu_colsolve.hip): columns a.col0 .. a.ncols - 1, four per wavefront
 void nnlm_tu_colsolve_row(const SweepArgs &a, size_t g_stride, hipStream_t st);
+// fp32-operand mode, row form (k_sweep_r.h, tu_sweepr.hip): nb workgroups of NW = 4 or 8 wavefronts of FOUR columns; a.k <= SWEEPR_KMAX; reads a.Graw
+#define SWEEPR_KMAX 50
+void nnlm_tu_sweep_r(const SweepArgs &a, int nb, int NW, hipStream_t st);
