@@ -110,8 +110,8 @@ def test_launch_policy_picks_the_cheapest_form(monkeypatch):
             assert (int(h.get_info("sweep_form_w")), int(h.get_info("sweep_groups_w"))) == want, (cus, n)
 
 
-@pytest.mark.parametrize("k", [5, 16, 17, 33, 48, 50, 51])
-@pytest.mark.parametrize("n", [100, 4096, 4100, 8192, 8200])
+@pytest.mark.parametrize("n,k", [(100, 5), (100, 16), (100, 48), (4096, 50), (4100, 50), (8192, 50), (8200, 50), (4100, 17), (8192, 33),
+                                 (4100, 51), (1000, 32), (3000, 49)])
 def test_fp32_sweep_takes_the_row_form_while_it_is_one_round_of_wavefronts(n, k):
     """fp32-operand mode, dense SCD: up to 16 columns per CU the sweep runs as sweep_row_kernel with four-wavefront workgroups (form 3,
     groups 4), up to 32 per CU with eight, beyond -- and for ranks above 50 -- as sweep_scd_f_kernel (form 2).  One W half-step with masks
